@@ -1,0 +1,162 @@
+/*
+ * rt_abi.h -- C ABI of the MI355X trace-loop library (librt_amd.so).
+ *
+ * This is the drop-in boundary for ONE hot path of Chang-Liu-TAMU/RT: the per-pixel trace
+ * loop (camera ray generation -> BVH traversal -> ray/triangle + ray/sphere hit -> material
+ * scatter -> sample accumulation).  Each entry point names the reference interface it replaces
+ * (paths relative to the reference root).  Plain C: pointers and sizes only, no C++ or torch
+ * types.  Every call returns 0 on success and a non-zero RT_E_* code on failure; nothing exits
+ * or throws across the boundary (the reference prints and exit(99)s, include/RT/common.h:26-36).
+ * rt_last_error() returns the text of the last failure on a context.
+ *
+ * One context drives one GPU.  Calls on one context must not overlap; create / resize / render
+ * may arrive from different host threads (the reference calls them from its main, console and
+ * worker threads: main.cpp:195-220,712; src/pbrt/pbrt_engine.cu:148), so every call makes its
+ * device current first.
+ *
+ * There is NO CPU fallback: if no HIP device is usable, rt_create fails.
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+enum {
+    RT_OK = 0,
+    RT_E_ARG = 1,      /* bad argument / call order */
+    RT_E_HIP = 2,      /* HIP runtime error (text in rt_last_error) */
+    RT_E_UNSUPPORTED = 3, /* input outside the supported subset (textures, sphere as tri[0], ...) */
+    RT_E_LIMIT = 4     /* a size limit was exceeded */
+};
+
+/* The reference's Triangle record, taken unchanged: include/RT/triangle.h:345-354
+ * (v0,v1,v2,normal,edge1,edge2,u,v,n0,n1,n2 as float[3]; calNormal,matType,shapeType,texIdx).
+ * shapeType 0 = triangle, 1 = sphere (centre v0, radius v1[0]).  148 bytes. */
+typedef struct rt_triangle148 {
+    float v0[3], v1[3], v2[3];
+    float normal[3];
+    float edge1[3], edge2[3];
+    float u[3], v[3];
+    float n0[3], n1[3], n2[3];
+    int32_t calNormal, matType, shapeType, texIdx;
+} rt_triangle148;
+
+/* The reference's bvh_node: include/RT/triangle.h:364-391.  Post-order array, root last;
+ * leaf iff left == right, and then left is the triangle index.  32 bytes. */
+typedef struct rt_bvh_node32 {
+    float box_min[3], box_max[3];
+    int32_t left, right;
+} rt_bvh_node32;
+
+/* POD form of one entry of the reference's device-heap material table
+ * (include/RT/material.h:86-218; table built by material_init, pbrt_engine.cu:25-47). */
+enum { RT_MAT_LAMBERTIAN = 0, RT_MAT_METAL = 1, RT_MAT_DIELECTRIC = 2, RT_MAT_LIGHT = 3 };
+typedef struct rt_material {
+    int32_t kind;
+    float albedo[3];
+    float param; /* metal: fuzz (already clamped to <= 1); dielectric: ref_idx */
+} rt_material;
+#define RT_MAT_NUM 50 /* MAT_NUM, include/RT/pbrt_engine.h:28 */
+
+typedef struct rt_stats {
+    uint64_t rays;        /* closest-hit queries (= hit() calls, pbrt_engine.cu:371) of the last launch */
+    double kernel_ms;     /* duration of the trace kernel, HIP events on the context's stream */
+    double total_ms;      /* whole call, host clock */
+    uint64_t wide_nodes;  /* device BVH size */
+    uint64_t prims;
+    int32_t stack_entries; /* LDS stack entries per lane */
+    int32_t reserved;
+} rt_stats;
+
+typedef struct rt_ctx rt_ctx;
+
+/* PbrtEngine::getInstance / ctor (include/RT/pbrt_engine.h:53-58, pbrt_engine.cu:65-67).
+ * device_id: HIP device ordinal.  Defaults as the reference: 640x360, 10 spp, depth 50. */
+int rt_create(rt_ctx **out, int device_id);
+/* ~PbrtEngine / __releaseMemory (pbrt_engine.h:60-62,164-182) */
+int rt_destroy(rt_ctx *ctx);
+const char *rt_last_error(rt_ctx *ctx);
+int rt_abi_version(void);
+
+/* setNx/setNy/setNs + uponPixelNumChange (pbrt_engine.h:65-84; refreshPixelNum pbrt_engine.cu:70-86).
+ * (Re)allocates the device framebuffer.  The reference's per-pixel global scratch
+ * (__allocateCudaStackMemory, pbrt_engine.cu:219-236) has no counterpart: stacks live in LDS. */
+int rt_resize(rt_ctx *ctx, int nx, int ny, int ns);
+
+/* m_vecTriangles after __genTrianglesFromScene (pbrt_engine.cu:167-178): n records, the mesh
+ * named "light" first.  Copied during the call.  tri[0] must be a triangle (it is the hard-coded
+ * light of pbrt_engine.cu:464,502); texIdx must be -1 on every record (textures out of scope). */
+int rt_set_scene(rt_ctx *ctx, const rt_triangle148 *tris, int n);
+
+/* __genBvhNodes (pbrt_engine.cu:181-202): bit-exact host builder (make_bvh_nodes, :335-368, with
+ * glibc rand() in its default state and libstdc++ std::sort, both restated), then wide-ify and
+ * upload.  rand_calls_before: how many rand() calls preceded the build in the caller's process
+ * (the reference shares rand() with scene setup, main.cpp:449-474); 0 = default state. */
+int rt_build_bvh(rt_ctx *ctx, int64_t rand_calls_before);
+/* Inject a node array built elsewhere (e.g. by the reference's own make_bvh_nodes) instead. */
+int rt_set_bvh_nodes(rt_ctx *ctx, const rt_bvh_node32 *nodes, int m);
+/* Read back the binary node array (m = 2n-1). cap = capacity of out in nodes. */
+int rt_get_bvh_nodes(rt_ctx *ctx, rt_bvh_node32 *out, int cap, int *m);
+
+/* material_init + rand_init (pbrt_engine.cu:25-47,597-601) as a host-side table. */
+int rt_default_materials(rt_material out[RT_MAT_NUM]);
+int rt_set_materials(rt_ctx *ctx, const rt_material *mats, int n);
+
+/* camera_update (pbrt_engine.cu:626-632) -> camera::update (include/RT/rt_camera.h:37-52).
+ * vfov is accepted and, like the reference (:629), ignored: the field of view is 40 degrees
+ * unless RT_OPT_HONOR_VFOV is set.  aspect = nx/ny of the last rt_resize. */
+int rt_set_camera(rt_ctx *ctx, const float lookfrom[3], const float lookat[3], float vfov, float dist_to_focus,
+                  float aperture);
+
+enum {
+    RT_OPT_MAX_DEPTH = 1,   /* ITER_NUM, pbrt_engine.cu:458 (default 50) */
+    RT_OPT_HONOR_VFOV = 2,  /* default 0 */
+    RT_OPT_LEAF_SIZE = 3,   /* primitives per device leaf, 1..8 (default 4); applies at next build */
+    RT_OPT_BOX_MODE = 4,    /* 0 = re-fitted boxes + one small pad (default), 1 = the reference's
+                               cumulatively padded boxes (triangle.h:28-31,76-85) */
+    RT_OPT_SHARD_RANK = 5,  /* multi-GPU tile sharding: this context renders the 8x8 tiles with */
+    RT_OPT_SHARD_WORLD = 6, /*   tile_index % world == rank; other pixels are written as 0 */
+    RT_OPT_KERNEL = 7       /* path kernel variant, see DESIGN.md (default 0) */
+};
+int rt_set_option(rt_ctx *ctx, int option, int64_t value);
+int rt_get_option(rt_ctx *ctx, int option, int64_t *value);
+
+/* render<<<>>> + cudaDeviceSynchronize + D2H copy (pbrt_engine.cu:110-122).  fb_rgb: nx*ny*3
+ * floats, pixel_index = j*nx + i, row j = 0 at the BOTTOM (the PPM writer flips).  Synchronous. */
+int rt_render(rt_ctx *ctx, float *fb_rgb_host, rt_stats *stats);
+/* Same, but the frame stays in device memory the caller owns (nx*ny*3 floats on this context's
+ * device); the call returns after the kernel has completed. */
+int rt_render_device(rt_ctx *ctx, float *fb_rgb_device, rt_stats *stats);
+
+/* Parity hook (no reference counterpart): the primary ray of sample 0 of every pixel
+ * (pbrt_engine.cu:584-586), closest hit via hit() (:371).  tri_id = index into the rt_set_scene
+ * array, -1 on a miss; t = rec.t (0 on a miss).  Host buffers of nx*ny. */
+int rt_trace_primary(rt_ctx *ctx, int32_t *tri_id_host, float *t_host, rt_stats *stats);
+/* Closest hit for caller-supplied rays (origin[3], direction[3] per ray, host memory). */
+int rt_trace_rays(rt_ctx *ctx, const float *org_dir6, int n_rays, int32_t *tri_id_host, float *t_host,
+                  rt_stats *stats);
+
+/* PPM writer of __renderScene (pbrt_engine.cu:123-133): "P3", rows top-down from j = ny-1,
+ * int(255.99*c), one pixel per line, no gamma. */
+int rt_write_ppm(const char *path, const float *fb_rgb, int nx, int ny);
+
+/* Test hooks for the restated toolchain pieces the builder depends on. */
+int rt_test_glibc_rand(uint32_t seed, int n, int32_t *out);
+int rt_test_introsort(const float *key, int32_t *idx, int n);
+/* The host builder alone (no GPU needed): out must hold 2n-1 nodes. */
+int rt_test_build_bvh(const rt_triangle148 *tris, int n, int64_t rand_calls_before, rt_bvh_node32 *out);
+/* The device layout alone (no GPU needed).  Sizes first (pass NULL buffers), then the copies:
+ * wide_nodes: 128 bytes each; prims: 48 bytes each (DFS leaf order); info[4] = {n_wide, n_prims,
+ * depth, stack_entries}. */
+int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size,
+                        int box_mode, void *wide_nodes, void *prims, int32_t info[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,537 @@
+// kernels.hip -- hand-written HIP for gfx950 (MI355X): the per-pixel trace loop.
+//
+// What is parity-critical and what is not:
+//   * Primitive intersection (ray/triangle, ray/sphere), camera rays, RNG, material scatter and
+//     sample accumulation follow the reference's float/double operation order exactly
+//     (file:line cited per function) and are compiled WITHOUT fused multiply-add
+//     (-ffp-contract=off on the command line and the pragma below).  Results must be bit-identical
+//     to the CPU oracle.
+//   * Box tests are NOT parity-critical: any conservative culling returns the same closest hit
+//     (min t, ties to the lower DFS-leaf rank == lower index in the re-ordered primitive array).
+//     They use explicit v_fma_f32 (__builtin_fmaf), approximate reciprocals and re-fitted boxes.
+//
+// Execution shape: one 64-lane wavefront per workgroup = one 8x8 pixel tile; per-lane traversal
+// stack in LDS at [entry][lane] (bank-conflict-free: consecutive lanes, consecutive banks); block ->
+// tile mapping is XCD-aware (blocks b and b+8 share an XCD's L2, so each XCD gets one contiguous
+// band of tiles).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+#include "kernels.h"
+#include "rt_shared_math.h"
+#include "rt_types.h"
+
+#pragma clang fp contract(off)
+
+namespace rtamd {
+
+// ------------------------------------------------------------------ vec3 (reference include/RT/vec3.h)
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 mk(float a, float b, float c) { return V3{a, b, c}; }
+__device__ __forceinline__ V3 ldv(const float *p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 vadd(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 vsub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 vmul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 vscl(float t, V3 v) { return mk(t * v.x, t * v.y, t * v.z); }
+__device__ __forceinline__ V3 vdiv(V3 v, float t) { return mk(v.x / t, v.y / t, v.z / t); } // three divides, vec3.h:101
+__device__ __forceinline__ V3 vneg(V3 v) { return mk(-v.x, -v.y, -v.z); }
+__device__ __forceinline__ float vdot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 vcross(V3 a, V3 b) { // vec3.h:113-117
+    return mk(a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float vsqlen(V3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }
+__device__ __forceinline__ float vlen(V3 v) { return __builtin_sqrtf(vsqlen(v)); }
+__device__ __forceinline__ V3 vunit(V3 v) { return vdiv(v, vlen(v)); }
+__device__ __forceinline__ float abs_ref(float f) { return (double)f > 0.0 ? f : -f; } // cuAbs, vec3.h:58
+__device__ __forceinline__ void clip_color(V3 &v) {                                    // vec3.h:52-56
+    v.x = (double)v.x > 1.0 ? 1.0f : v.x;
+    v.y = (double)v.y > 1.0 ? 1.0f : v.y;
+    v.z = (double)v.z > 1.0 ? 1.0f : v.z;
+}
+#define RT_REF_PI 3.1415926 /* vec3.h:16 */
+
+// ------------------------------------------------------------------ closest hit
+struct Ray {
+    V3 o, d;
+};
+struct Hit {
+    float t;
+    int rank; // index into the DFS-ordered primitive array; 0x7fffffff = miss
+};
+#define RT_NO_HIT 0x7fffffff
+
+// Primitive test.  Triangle: Triangle::hit, include/RT/triangle.h:136-179 (Moeller-Trumbore, no
+// determinant epsilon, two-sided).  Sphere: triangle.h:180-213 (near root only; the "second root"
+// repeats the minus sign).  t interval is the reference's fixed (0.001, FLT_MAX).
+__device__ __forceinline__ bool prim_test(const float4 *__restrict__ prims, uint32_t rank, const Ray &r, float &t_out) {
+    const float4 *p = prims + 3 * (size_t)rank;
+    float4 A = p[0], B = p[1], C = p[2];
+    if (__float_as_int(C.y) == 0) {
+        V3 v0 = mk(A.x, A.y, A.z), e1 = mk(A.w, B.x, B.y), e2 = mk(B.z, B.w, C.x);
+        V3 tvec = vsub(r.o, v0);
+        V3 pvec = vcross(r.d, e2);
+        float det = vdot(e1, pvec);
+        det = 1.0f / det;
+        float u = vdot(tvec, pvec) * det;
+        if (u < 0.0f || u > 1.0f) return false;
+        V3 qvec = vcross(tvec, e1);
+        float v = vdot(r.d, qvec) * det;
+        if (v < 0.0f || (u + v) > 1.0f) return false;
+        float t = vdot(e2, qvec) * det;
+        if (t <= 0.001f || t >= FLT_MAX) return false;
+        t_out = t;
+        return true;
+    } else {
+        V3 c = mk(A.x, A.y, A.z);
+        float radius = A.w;
+        V3 oc = vsub(r.o, c);
+        float a = vdot(r.d, r.d);
+        float b = (float)(2.0 * (double)vdot(oc, r.d));
+        float cc = vdot(oc, oc) - radius * radius;
+        float disc = b * b - 4 * a * cc;
+        if (disc > 0) {
+            float tem = (float)((double)(-b - __builtin_sqrtf(disc)) / (2.0 * (double)a));
+            if (tem < FLT_MAX && tem > 0.001f) {
+                t_out = tem;
+                return true;
+            }
+        }
+        return false;
+    }
+}
+
+__device__ __forceinline__ float safe_inv(float d) {
+    float inv = __builtin_amdgcn_rcpf(d);
+    if (!(__builtin_fabsf(inv) <= 1e18f)) inv = __builtin_copysignf(1e18f, d);
+    return inv;
+}
+
+__device__ __forceinline__ uint32_t sel4(uint4 c, uint32_t s) {
+    uint32_t lo = (s & 1) ? c.y : c.x;
+    uint32_t hi = (s & 1) ? c.w : c.z;
+    return (s & 2) ? hi : lo;
+}
+
+#define RT_CSWAP(a, b)                                                                                                \
+    {                                                                                                                  \
+        uint32_t lo_ = min(a, b);                                                                                      \
+        uint32_t hi_ = max(a, b);                                                                                      \
+        a = lo_;                                                                                                       \
+        b = hi_;                                                                                                       \
+    }
+
+// while-while style traversal of the 4-wide BVH with a per-lane LDS stack.
+// stack: this lane's column; entry k lives at stack[k * 64].
+__device__ __forceinline__ Hit closest_hit(const float4 *__restrict__ nodes, const float4 *__restrict__ prims,
+                                           const Ray &r, uint32_t *stack) {
+    const float idx = safe_inv(r.d.x), idy = safe_inv(r.d.y), idz = safe_inv(r.d.z);
+    const float nox = -r.o.x * idx, noy = -r.o.y * idy, noz = -r.o.z * idz;
+    // near / far plane vectors by direction sign (float4 index inside the node)
+    const int nxi = r.d.x < 0.0f ? 3 : 0, fxi = 3 - nxi;
+    const int nyi = r.d.y < 0.0f ? 4 : 1, fyi = 5 - nyi;
+    const int nzi = r.d.z < 0.0f ? 5 : 2, fzi = 7 - nzi;
+
+    float best_t = FLT_MAX;
+    int best_rank = RT_NO_HIT;
+    uint32_t cur = 0; // root node
+    int sp = 0;
+    for (;;) {
+        if (!(cur & kLeafBit)) {
+            const float4 *n = nodes + 8 * (size_t)cur;
+            const float4 nx = n[nxi], ny = n[nyi], nz = n[nzi];
+            const float4 fx = n[fxi], fy = n[fyi], fz = n[fzi];
+            const uint4 ch = *reinterpret_cast<const uint4 *>(n + 6);
+            uint32_t k0, k1, k2, k3;
+#define RT_SLAB(K, C, I)                                                                                               \
+    {                                                                                                                  \
+        float tn = fmaxf(fmaxf(__builtin_fmaf(nx.C, idx, nox), __builtin_fmaf(ny.C, idy, noy)),                        \
+                         fmaxf(__builtin_fmaf(nz.C, idz, noz), 0.001f));                                               \
+        float tf = fminf(fminf(__builtin_fmaf(fx.C, idx, nox), __builtin_fmaf(fy.C, idy, noy)),                        \
+                         fminf(__builtin_fmaf(fz.C, idz, noz), best_t));                                               \
+        K = (tn <= tf) ? ((__float_as_uint(tn) & ~3u) | I) : 0xFFFFFFFFu;                                              \
+    }
+            RT_SLAB(k0, x, 0u)
+            RT_SLAB(k1, y, 1u)
+            RT_SLAB(k2, z, 2u)
+            RT_SLAB(k3, w, 3u)
+#undef RT_SLAB
+            RT_CSWAP(k0, k1)
+            RT_CSWAP(k2, k3)
+            RT_CSWAP(k0, k2)
+            RT_CSWAP(k1, k3)
+            RT_CSWAP(k1, k2)
+            if (k0 != 0xFFFFFFFFu) {
+                cur = sel4(ch, k0 & 3u);
+                if (k1 != 0xFFFFFFFFu) {
+                    if (k2 != 0xFFFFFFFFu) {
+                        if (k3 != 0xFFFFFFFFu) {
+                            stack[sp * 64] = sel4(ch, k3 & 3u);
+                            sp++;
+                        }
+                        stack[sp * 64] = sel4(ch, k2 & 3u);
+                        sp++;
+                    }
+                    stack[sp * 64] = sel4(ch, k1 & 3u);
+                    sp++;
+                }
+                continue;
+            }
+        } else {
+            const uint32_t start = cur & kLeafStartMask;
+            const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt; i++) {
+                float t;
+                if (prim_test(prims, start + i, r, t)) {
+                    int rk = (int)(start + i);
+                    // min t; ties to the earlier DFS leaf (pbrt_engine.cu:421-438)
+                    if (t < best_t || (t == best_t && rk < best_rank)) {
+                        best_t = t;
+                        best_rank = rk;
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = stack[sp * 64];
+    }
+    Hit h;
+    h.t = best_t;
+    h.rank = best_rank;
+    return h;
+}
+
+// ------------------------------------------------------------------ camera (reference rt_camera.h:9-60)
+__device__ __forceinline__ V3 disk_sample(Rng &g) { // random_in_unit_disk_d, x drawn first
+    V3 p;
+    do {
+        float a = rng_uniform(g);
+        float b = rng_uniform(g);
+        p = vsub(vscl(2.0f, mk(a, b, 0.0f)), mk(1.0f, 1.0f, 0.0f));
+    } while (vdot(p, p) >= 1.0f);
+    return p;
+}
+__device__ __forceinline__ Ray camera_ray(const DevCamera &c, float s, float t, Rng &g) { // camera::get_ray
+    V3 rd = vscl(c.lens_radius, disk_sample(g));
+    V3 cu = ldv(c.u), cv = ldv(c.v), org = ldv(c.origin);
+    V3 offset = vadd(vscl(rd.x, cu), vscl(rd.y, cv));
+    (void)rng_uniform(g); // ray time, rt_camera.h:58: consumed, never read by hit()
+    Ray r;
+    r.o = vadd(org, offset);
+    r.d = vsub(vsub(vadd(vadd(ldv(c.lower_left), vscl(s, ldv(c.horizontal))), vscl(t, ldv(c.vertical))), org), offset);
+    return r;
+}
+__device__ __forceinline__ Ray primary_ray(const DevCamera &c, int i, int j, int nx, int ny, Rng &g) {
+    float u = ((float)i + rng_uniform(g)) / (float)nx; // pbrt_engine.cu:584-585
+    float v = ((float)j + rng_uniform(g)) / (float)ny;
+    return camera_ray(c, u, v, g);
+}
+
+// ------------------------------------------------------------------ sampling (utilities.h:25-59, utilities.cu:18-59)
+struct Onb {
+    V3 u, v, w;
+};
+__device__ __forceinline__ Onb onb_from_w(V3 n) {
+    Onb b;
+    b.w = vunit(n);
+    V3 a = ((double)abs_ref(b.w.x) > 0.9) ? mk(0, 1, 0) : mk(1, 0, 0);
+    b.v = vunit(vcross(b.w, a));
+    b.u = vcross(b.w, b.v);
+    return b;
+}
+__device__ __forceinline__ V3 cosine_generate(const Onb &b, Rng &g) {
+    float r1 = rng_uniform(g);
+    float r2 = rng_uniform(g);
+    float z = __builtin_sqrtf(1 - r2);
+    float phi = (float)(2 * RT_REF_PI * (double)r1);
+    double sn, cs;
+    sincos_sh((double)phi, sn, cs);
+    float sr2 = __builtin_sqrtf(r2);
+    float x = (float)((double)(float)cs * 2.0 * (double)sr2); // the factor 2 is the reference's (utilities.cu:23-24)
+    float y = (float)((double)(float)sn * 2.0 * (double)sr2);
+    return vadd(vadd(vscl(x, b.u), vscl(y, b.v)), vscl(z, b.w));
+}
+__device__ __forceinline__ float cosine_value(const Onb &b, V3 dir) {
+    float c = vdot(vunit(dir), b.w);
+    return (float)(c > 0 ? (double)c / RT_REF_PI : 0.0);
+}
+__device__ __forceinline__ V3 ball_sample(Rng &g) { // random_in_unit_sphere, material.h:27-33
+    V3 p;
+    do {
+        float a = rng_uniform(g);
+        float b = rng_uniform(g);
+        float c = rng_uniform(g);
+        p = vsub(vscl(2.0f, mk(a, b, c)), mk(1, 1, 1));
+    } while (vsqlen(p) >= 1.0f);
+    return p;
+}
+__device__ __forceinline__ V3 reflect_ref(V3 v, V3 n) { return vsub(v, vscl(2.0f * vdot(v, n), n)); }
+__device__ __forceinline__ bool refract_ref(V3 v, V3 n, float ni_over_nt, V3 &out) { // material.h:13-23
+    V3 uv = vunit(v);
+    float dt = vdot(uv, n);
+    float disc = 1.0f - ni_over_nt * ni_over_nt * (1 - dt * dt);
+    if (disc > 0) {
+        out = vsub(vscl(ni_over_nt, vsub(uv, vscl(dt, n))), vscl(__builtin_sqrtf(disc), n));
+        return true;
+    }
+    return false;
+}
+__device__ __forceinline__ float schlick_ref(float cosine, float ref_idx) { // material.h:7-11
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * pow5_sh(1.0f - cosine);
+}
+
+// One bounce of color() (pbrt_engine.cu:467-560) after hit() has returned.
+// Returns true if the path continues with `cur` replaced; false if the sample is finished, in which
+// case `thr` is the sample's value BEFORE the per-sample clamp, and `clamp` says whether to apply it
+// (the pdf < 1e-6 exit at :519-521 returns black unclamped).
+__device__ __forceinline__ bool shade_bounce(const KernelScene &S, const Hit &h, Ray &cur, V3 &thr, Rng &g, bool &clamp) {
+    clamp = true;
+    if (h.rank == RT_NO_HIT) { // sky, :554-558
+        V3 ud = vunit(cur.d);
+        float t = 0.5f * (ud.y + 1.0f);
+        V3 c = vadd(vscl(1.0f - t, mk(1.0f, 1.0f, 1.0f)), vscl(t, mk(0.5f, 0.7f, 1.0f)));
+        thr = vmul(thr, c);
+        return false;
+    }
+    // hit record: p, face-forwarded normal (triangle.h:163-173) or sphere normal (:193)
+    const float4 pc = S.prims[3 * (size_t)h.rank + 2];
+    const int shape = __float_as_int(pc.y);
+    const int mat_id = __float_as_int(pc.w);
+    V3 p = vadd(cur.o, vscl(h.t, cur.d));
+    V3 n;
+    if (shape == 0) {
+        const float4 sh = S.shade[h.rank];
+        V3 gn = mk(sh.x, sh.y, sh.z);
+        n = (vdot(cur.d, gn) < 0.0f) ? gn : vneg(gn);
+    } else {
+        const float4 pa = S.prims[3 * (size_t)h.rank];
+        n = vdiv(vsub(p, mk(pa.x, pa.y, pa.z)), pa.w);
+    }
+    const DevMat m = S.mats[mat_id];
+    const V3 alb = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+    if (m.kind == RT_MAT_LAMBERTIAN) { // material.h:95-116 + pbrt_engine.cu:500-525
+        Onb b = onb_from_w(n);
+        (void)rng_uniform(g); // :505
+        V3 dir = cosine_generate(b, g);
+        // pdf = 1*p1.value + 0*p2.value (:518).  p2 = tri[0].pdf_value is finite for a triangle tri[0]
+        // (rt_set_scene enforces that), so it adds exactly +0; a NaN direction poisons p1 the same way.
+        float pdf = cosine_value(b, dir);
+        if ((double)pdf < 1e-6) {
+            thr = mk(0, 0, 0);
+            clamp = false;
+            return false;
+        }
+        float cosine = vdot(n, vunit(dir)); // lambertian::scatter_pdf
+        if ((double)cosine < 0.0) cosine = 0.0f;
+        float spdf = (float)((double)cosine / 3.1415926);
+        thr = vmul(thr, vdiv(vscl(spdf, alb), pdf));
+        cur.o = p;
+        cur.d = dir;
+        return true;
+    } else if (m.kind == RT_MAT_METAL) { // material.h:163-171
+        V3 reflected = reflect_ref(vunit(cur.d), n);
+        V3 fz = ball_sample(g);
+        V3 dir = vadd(reflected, vscl(m.param, fz));
+        thr = vmul(thr, alb);
+        if (!(vdot(dir, n) > 0.0f)) return false;
+        cur.o = p;
+        cur.d = dir;
+        return true;
+    } else if (m.kind == RT_MAT_DIELECTRIC) { // material.h:180-215
+        float ref_idx = m.param;
+        V3 outward;
+        V3 reflected = reflect_ref(cur.d, n);
+        float ni_over_nt;
+        V3 refracted = mk(0, 0, 0);
+        float reflect_prob;
+        float cosine;
+        float dn = vdot(cur.d, n);
+        if (dn > 0.0f) {
+            outward = vneg(n);
+            ni_over_nt = ref_idx;
+            cosine = dn / vlen(cur.d);
+            cosine = __builtin_sqrtf(1.0f - ref_idx * ref_idx * (1 - cosine * cosine));
+        } else {
+            outward = n;
+            ni_over_nt = 1.0f / ref_idx;
+            cosine = -dn / vlen(cur.d);
+        }
+        if (refract_ref(cur.d, outward, ni_over_nt, refracted))
+            reflect_prob = schlick_ref(cosine, ref_idx);
+        else
+            reflect_prob = 1.0f;
+        V3 dir = (rng_uniform(g) < reflect_prob) ? reflected : refracted;
+        thr = vmul(thr, mk(1.0f, 1.0f, 1.0f));
+        cur.o = p;
+        cur.d = dir;
+        return true;
+    } else { // diffusive_light, material.h:137-148 -> pbrt_engine.cu:544-545
+        thr = vmul(thr, alb);
+        return false;
+    }
+}
+
+// ------------------------------------------------------------------ block -> tile mapping
+// Blocks b and b+8 run on the same XCD (round-robin dispatch); give each XCD one contiguous run of
+// this context's tiles so that its 4 MiB L2 sees one band of the image.  Bijective for any count.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
+    uint32_t q = n >> 3, r = n & 7u;
+    uint32_t xcd = b & 7u;
+    uint32_t base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + (b >> 3);
+}
+
+__device__ __forceinline__ bool tile_pixel(const KernelFrame &F, int &i, int &j) {
+    uint32_t local = xcd_remap(blockIdx.x, F.n_local_tiles);
+    uint32_t g = local * (uint32_t)F.shard_world + (uint32_t)F.shard_rank;
+    int tx = (int)(g % (uint32_t)F.tiles_x), ty = (int)(g / (uint32_t)F.tiles_x);
+    int lane = threadIdx.x;
+    i = tx * 8 + (lane & 7);
+    j = ty * 8 + (lane >> 3);
+    return i < F.nx && j < F.ny;
+}
+
+__device__ __forceinline__ void add_rays(unsigned long long *counter, uint32_t n) {
+    // wave-level sum, then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off);
+    if (threadIdx.x == 0 && n) atomicAdd(counter, (unsigned long long)n);
+}
+
+extern __shared__ uint32_t s_stack[];
+
+// ------------------------------------------------------------------ kernels
+// Primary ray of sample 0 of every pixel: parity hook (hit ids and t).
+__global__ void __launch_bounds__(64) k_trace_primary(KernelScene S, KernelFrame F, int32_t *ids, float *ts) {
+    int i, j;
+    bool in = tile_pixel(F, i, j);
+    uint32_t nr = 0;
+    if (in) {
+        int pixel_index = j * F.nx + i;
+        Rng g;
+        rng_init(g, (uint64_t)(1995 + pixel_index)); // pbrt_engine.cu:580
+        Ray r = primary_ray(F.cam, i, j, F.nx, F.ny, g);
+        Hit h = closest_hit(S.nodes, S.prims, r, s_stack + threadIdx.x);
+        nr = 1;
+        if (h.rank != RT_NO_HIT) {
+            ids[pixel_index] = __float_as_int(S.prims[3 * (size_t)h.rank + 2].z);
+            ts[pixel_index] = h.t;
+        } else {
+            ids[pixel_index] = -1;
+            ts[pixel_index] = 0.0f;
+        }
+    }
+    add_rays(F.ray_counter, nr);
+}
+
+// Closest hit for caller-supplied rays.
+__global__ void __launch_bounds__(64) k_trace_rays(KernelScene S, const float *org_dir6, int n, int32_t *ids, float *ts,
+                                                   unsigned long long *counter) {
+    int k = blockIdx.x * 64 + threadIdx.x;
+    uint32_t nr = 0;
+    if (k < n) {
+        Ray r;
+        r.o = mk(org_dir6[6 * (size_t)k + 0], org_dir6[6 * (size_t)k + 1], org_dir6[6 * (size_t)k + 2]);
+        r.d = mk(org_dir6[6 * (size_t)k + 3], org_dir6[6 * (size_t)k + 4], org_dir6[6 * (size_t)k + 5]);
+        Hit h = closest_hit(S.nodes, S.prims, r, s_stack + threadIdx.x);
+        nr = 1;
+        if (h.rank != RT_NO_HIT) {
+            ids[k] = __float_as_int(S.prims[3 * (size_t)h.rank + 2].z);
+            ts[k] = h.t;
+        } else {
+            ids[k] = -1;
+            ts[k] = 0.0f;
+        }
+    }
+    add_rays(counter, nr);
+}
+
+// render(), pbrt_engine.cu:569-595, as a per-lane state machine: every loop trip traces ONE ray of the
+// lane's current path (primary or bounce), so lanes whose paths end early start their next sample at
+// once instead of idling until the longest path of the wave ends.  RNG order per pixel is the
+// reference's: samples serial, draws in path order.
+__global__ void __launch_bounds__(64) k_render(KernelScene S, KernelFrame F, float *fb) {
+    int i, j;
+    bool in = tile_pixel(F, i, j);
+    uint32_t nr = 0;
+    if (in) {
+        const int pixel_index = j * F.nx + i;
+        Rng g;
+        rng_init(g, (uint64_t)(1995 + pixel_index));
+        V3 col = mk(0, 0, 0);
+        int k = 0;
+        int bounce = 0;
+        Ray cur;
+        cur.o = mk(0, 0, 0);
+        cur.d = mk(0, 0, 1);
+        V3 thr = mk(1, 1, 1);
+        bool fresh = true;
+        while (k < F.ns) {
+            if (fresh) {
+                cur = primary_ray(F.cam, i, j, F.nx, F.ny, g);
+                thr = mk(1.0f, 1.0f, 1.0f);
+                bounce = 0;
+                fresh = false;
+            }
+            Hit h = closest_hit(S.nodes, S.prims, cur, s_stack + threadIdx.x);
+            nr++;
+            bool clamp;
+            bool go_on = shade_bounce(S, h, cur, thr, g, clamp);
+            bounce++;
+            if (!go_on || bounce >= F.max_depth) { // ITER_NUM exhausted: falls to RETURN_COLOR with the throughput
+                if (clamp) clip_color(thr);       // per-SAMPLE clamp, :564
+                col = vadd(col, thr);
+                k++;
+                fresh = true;
+            }
+        }
+        { // col /= float(ns): multiply by float(1.0/ns), vec3.h:158-165
+            float kk = (float)(1.0 / (double)(float)F.ns);
+            col = mk(col.x * kk, col.y * kk, col.z * kk);
+        }
+        clip_color(col); // :591-593
+        fb[3 * (size_t)pixel_index + 0] = col.x;
+        fb[3 * (size_t)pixel_index + 1] = col.y;
+        fb[3 * (size_t)pixel_index + 2] = col.z;
+    }
+    add_rays(F.ray_counter, nr);
+}
+
+// ------------------------------------------------------------------ launchers (host)
+static inline hipError_t lds_bytes_ok(int stack_entries, size_t &bytes) {
+    bytes = (size_t)stack_entries * 64 * sizeof(uint32_t);
+    return bytes <= 64 * 1024 ? hipSuccess : hipErrorInvalidValue;
+}
+
+hipError_t launch_trace_primary(const KernelScene &S, const KernelFrame &F, int stack_entries, int32_t *ids, float *ts,
+                                hipStream_t stream) {
+    size_t lds;
+    if (lds_bytes_ok(stack_entries, lds) != hipSuccess) return hipErrorInvalidValue;
+    if (F.n_local_tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_trace_primary, dim3(F.n_local_tiles), dim3(64), lds, stream, S, F, ids, ts);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace_rays(const KernelScene &S, int stack_entries, const float *org_dir6, int n, int32_t *ids,
+                             float *ts, unsigned long long *counter, hipStream_t stream) {
+    size_t lds;
+    if (lds_bytes_ok(stack_entries, lds) != hipSuccess) return hipErrorInvalidValue;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_trace_rays, dim3((n + 63) / 64), dim3(64), lds, stream, S, org_dir6, n, ids, ts, counter);
+    return hipGetLastError();
+}
+
+hipError_t launch_render(const KernelScene &S, const KernelFrame &F, int stack_entries, float *fb, hipStream_t stream) {
+    size_t lds;
+    if (lds_bytes_ok(stack_entries, lds) != hipSuccess) return hipErrorInvalidValue;
+    if (F.n_local_tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_render, dim3(F.n_local_tiles), dim3(64), lds, stream, S, F, fb);
+    return hipGetLastError();
+}
+
+} // namespace rtamd

@@ -1,0 +1,614 @@
+// rt_abi.cpp -- the C ABI of include/rt_abi.h over the host builders and the HIP kernels.
+// Host code, compiled by hipcc with -ffp-contract=off (the camera basis is float arithmetic that must
+// match the reference's camera::update operation for operation).
+#include "../../include/rt_abi.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bvh_build.h"
+#include "kernels.h"
+#include "rt_shared_math.h"
+#include "rt_types.h"
+#include "wide_bvh.h"
+
+#pragma clang fp contract(off)
+
+using namespace rtamd;
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // NX/NY/NS, include/RT/pbrt_engine.h:24-26 ; ITER_NUM, pbrt_engine.cu:458
+    int nx = 640, ny = 360, ns = 10, max_depth = 50;
+    int honor_vfov = 0, leaf_size = 4, box_mode = 0, shard_rank = 0, shard_world = 1, kernel_variant = 0;
+
+    std::vector<rt_triangle148> tris;
+    std::vector<rt_bvh_node32> bnodes;
+    WideBvh wide;
+    bool scene_on_device = false;
+
+    void *d_nodes = nullptr, *d_prims = nullptr, *d_shade = nullptr;
+    DevMat *d_mats = nullptr;
+    float *d_fb = nullptr;
+    size_t fb_pixels = 0;
+    unsigned long long *d_counter = nullptr;
+
+    rt_material mats[RT_MAT_NUM];
+    bool mats_dirty = true;
+
+    bool cam_set = false;
+    float lookfrom[3], lookat[3], vfov = 40.0f, focus = 10.0f, aperture = 0.0f;
+
+    std::string err;
+};
+
+namespace {
+
+int fail(rt_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                                                \
+    do {                                                                                                               \
+        hipError_t e_ = (call);                                                                                        \
+        if (e_ != hipSuccess) {                                                                                        \
+            char buf_[512];                                                                                            \
+            snprintf(buf_, sizeof(buf_), "HIP error %d (%s) at %s:%d '%s'", (int)e_, hipGetErrorString(e_), __FILE__, \
+                     __LINE__, #call);                                                                                 \
+            return fail(c, RT_E_HIP, buf_);                                                                            \
+        }                                                                                                              \
+    } while (0)
+
+struct F3 {
+    float x, y, z;
+};
+inline F3 f3(const float *p) { return F3{p[0], p[1], p[2]}; }
+inline F3 sub(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline F3 scl(float t, F3 v) { return F3{t * v.x, t * v.y, t * v.z}; }
+inline F3 cross(F3 a, F3 b) { return F3{a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x}; }
+inline float length(F3 v) { return std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z); }
+inline F3 unit(F3 v) {
+    float l = length(v);
+    return F3{v.x / l, v.y / l, v.z / l};
+}
+inline void put(float *p, F3 v) {
+    p[0] = v.x;
+    p[1] = v.y;
+    p[2] = v.z;
+}
+
+// camera::update, include/RT/rt_camera.h:37-52, with vup = (0,1,0), t0 = 0, t1 = 1 (pbrt_engine.cu:629)
+void camera_basis(DevCamera &c, const float lookfrom[3], const float lookat[3], float vfov, float aspect, float aperture,
+                  float focus) {
+    const F3 vup{0.0f, 1.0f, 0.0f};
+    c.time0 = 0.0f;
+    c.time1 = 1.0f;
+    c.lens_radius = aperture / 2.0f;
+    float theta = (vfov / 180.f) * (float)3.1415926; // M_PI of vec3.h:16
+    float half_height = tan_sh(theta / 2.0f);
+    float half_width = aspect * half_height;
+    F3 org = f3(lookfrom);
+    F3 w = unit(sub(org, f3(lookat)));
+    F3 u = unit(cross(vup, w));
+    F3 v = cross(w, u);
+    F3 ll = sub(sub(sub(org, scl(half_width * focus, u)), scl(half_height * focus, v)), scl(focus, w));
+    put(c.origin, org);
+    put(c.lower_left, ll);
+    put(c.horizontal, scl(2.0f * half_width * focus, u));
+    put(c.vertical, scl(2.0f * half_height * focus, v));
+    put(c.u, u);
+    put(c.v, v);
+    put(c.w, w);
+}
+
+void free_scene(rt_ctx *c) {
+    if (c->d_nodes) (void)hipFree(c->d_nodes);
+    if (c->d_prims) (void)hipFree(c->d_prims);
+    if (c->d_shade) (void)hipFree(c->d_shade);
+    c->d_nodes = c->d_prims = c->d_shade = nullptr;
+    c->scene_on_device = false;
+}
+
+int upload_scene(rt_ctx *c) {
+    std::string err;
+    if (!build_wide_bvh(c->tris.data(), (int)c->tris.size(), c->bnodes.data(), (int)c->bnodes.size(), c->leaf_size,
+                        c->box_mode, c->wide, err))
+        return fail(c, RT_E_ARG, "wide BVH: " + err);
+    if ((size_t)c->wide.stack_entries * 64 * 4 > 64 * 1024) return fail(c, RT_E_LIMIT, "tree too deep for the LDS stack");
+    free_scene(c);
+    size_t nb = c->wide.nodes.size() * sizeof(WideNode), pb = c->wide.prims.size() * sizeof(DevPrim),
+           sb = c->wide.shade.size() * sizeof(DevShade);
+    HIPCHK(c, hipMalloc(&c->d_nodes, nb));
+    HIPCHK(c, hipMalloc(&c->d_prims, pb));
+    HIPCHK(c, hipMalloc(&c->d_shade, sb));
+    HIPCHK(c, hipMemcpyAsync(c->d_nodes, c->wide.nodes.data(), nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_prims, c->wide.prims.data(), pb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_shade, c->wide.shade.data(), sb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->scene_on_device = true;
+    return RT_OK;
+}
+
+int upload_mats(rt_ctx *c) {
+    if (!c->mats_dirty) return RT_OK;
+    DevMat tmp[RT_MAT_NUM];
+    for (int i = 0; i < RT_MAT_NUM; i++) {
+        tmp[i].kind = c->mats[i].kind;
+        for (int k = 0; k < 3; k++) tmp[i].albedo[k] = c->mats[i].albedo[k];
+        tmp[i].param = c->mats[i].param;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_mats, tmp, sizeof(tmp), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->mats_dirty = false;
+    return RT_OK;
+}
+
+int ensure_fb(rt_ctx *c) {
+    size_t px = (size_t)c->nx * c->ny;
+    if (c->d_fb && c->fb_pixels == px) return RT_OK;
+    if (c->d_fb) (void)hipFree(c->d_fb);
+    c->d_fb = nullptr;
+    c->fb_pixels = 0;
+    HIPCHK(c, hipMalloc((void **)&c->d_fb, px * 3 * sizeof(float)));
+    c->fb_pixels = px;
+    return RT_OK;
+}
+
+int ready_to_trace(rt_ctx *c) {
+    if (c->tris.empty()) return fail(c, RT_E_ARG, "no scene: call rt_set_scene first");
+    if (c->bnodes.empty()) return fail(c, RT_E_ARG, "no BVH: call rt_build_bvh or rt_set_bvh_nodes first");
+    if (!c->scene_on_device) {
+        int rc = upload_scene(c);
+        if (rc) return rc;
+    }
+    return upload_mats(c);
+}
+
+void fill_frame(rt_ctx *c, KernelFrame &F) {
+    float aspect = float(c->nx) / float(c->ny);
+    camera_basis(F.cam, c->lookfrom, c->lookat, c->honor_vfov ? c->vfov : 40.0f, aspect, c->aperture, c->focus);
+    F.nx = c->nx;
+    F.ny = c->ny;
+    F.ns = c->ns;
+    F.max_depth = c->max_depth;
+    F.tiles_x = (c->nx + 7) / 8;
+    F.tiles_y = (c->ny + 7) / 8;
+    long total = (long)F.tiles_x * F.tiles_y;
+    F.shard_rank = c->shard_rank;
+    F.shard_world = c->shard_world;
+    F.n_local_tiles = (int)((total - c->shard_rank + c->shard_world - 1) / c->shard_world);
+    F.ray_counter = c->d_counter;
+}
+
+KernelScene scene_of(rt_ctx *c) {
+    KernelScene S;
+    S.nodes = (const float4 *)c->d_nodes;
+    S.prims = (const float4 *)c->d_prims;
+    S.shade = (const float4 *)c->d_shade;
+    S.mats = c->d_mats;
+    return S;
+}
+
+void fill_stats(rt_ctx *c, rt_stats *st, uint64_t rays, float ms, double total_ms) {
+    if (!st) return;
+    st->rays = rays;
+    st->kernel_ms = ms;
+    st->total_ms = total_ms;
+    st->wide_nodes = c->wide.nodes.size();
+    st->prims = c->wide.prims.size();
+    st->stack_entries = c->wide.stack_entries;
+    st->reserved = 0;
+}
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+} // namespace
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_default_materials(rt_material out[RT_MAT_NUM]) {
+    if (!out) return RT_E_ARG;
+    // material_init, pbrt_engine.cu:25-47; the random entries come from ONE stream seeded 1995 (:599),
+    // drawn left to right: albedo x, y, z (then fuzz).
+    auto set = [&](int i, int kind, float r, float g, float b, float p) {
+        out[i].kind = kind;
+        out[i].albedo[0] = r;
+        out[i].albedo[1] = g;
+        out[i].albedo[2] = b;
+        out[i].param = p;
+    };
+    auto fuzz = [](float f) { return (double)f < 1.0 ? f : 1.0f; }; // metal ctor, material.h:160-162
+    set(0, RT_MAT_LAMBERTIAN, 0.5f, 0.5f, 0.5f, 0.0f);
+    set(1, RT_MAT_LAMBERTIAN, 0.2f, 0.4f, 0.1f, 0.0f);
+    set(2, RT_MAT_DIELECTRIC, 1.0f, 1.0f, 1.0f, 0.4f);
+    set(3, RT_MAT_LIGHT, 20.0f, 20.0f, 20.0f, 0.0f);
+    set(4, RT_MAT_METAL, 1.0f, (float)(182.0 / 255.0), (float)(193.0 / 255.0), fuzz((float)0.01));
+    set(5, RT_MAT_METAL, 0.8f, 0.85f, 0.88f, fuzz(0.0f));
+    set(6, RT_MAT_METAL, 0.7f, 0.6f, 0.5f, fuzz(0.0f));
+    set(7, RT_MAT_DIELECTRIC, 1.0f, 1.0f, 1.0f, 1.5f);
+    set(8, RT_MAT_LAMBERTIAN, 0.65f, 0.05f, 0.05f, 0.0f);
+    set(9, RT_MAT_LAMBERTIAN, 0.12f, 0.45f, 0.15f, 0.0f);
+    Rng g;
+    rng_init(g, 1995);
+    for (int i = 10; i < 30; i++) {
+        float r = rng_uniform(g), gg = rng_uniform(g), b = rng_uniform(g);
+        set(i, RT_MAT_LAMBERTIAN, r, gg, b, 0.0f);
+    }
+    for (int i = 30; i < 50; i++) {
+        float r = rng_uniform(g), gg = rng_uniform(g), b = rng_uniform(g);
+        float f = rng_uniform(g) / 50;
+        set(i, RT_MAT_METAL, r, gg, b, fuzz(f));
+    }
+    return RT_OK;
+}
+
+int rt_create(rt_ctx **out, int device_id) {
+    if (!out) return RT_E_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return RT_E_HIP; // no CPU fallback
+    if (device_id < 0 || device_id >= count) return RT_E_ARG;
+    rt_ctx *c = new rt_ctx();
+    c->device = device_id;
+    auto bail = [&](hipError_t e) {
+        (void)e;
+        delete c;
+        return RT_E_HIP;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail(e);
+    if ((e = hipStreamCreate(&c->stream)) != hipSuccess) return bail(e);
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail(e);
+    if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e);
+    if ((e = hipMalloc((void **)&c->d_counter, sizeof(unsigned long long))) != hipSuccess) return bail(e);
+    if ((e = hipMalloc((void **)&c->d_mats, sizeof(DevMat) * RT_MAT_NUM)) != hipSuccess) return bail(e);
+    rt_default_materials(c->mats);
+    *out = c;
+    return RT_OK;
+}
+
+int rt_destroy(rt_ctx *c) {
+    if (!c) return RT_E_ARG;
+    (void)hipSetDevice(c->device);
+    free_scene(c);
+    if (c->d_fb) (void)hipFree(c->d_fb);
+    if (c->d_mats) (void)hipFree(c->d_mats);
+    if (c->d_counter) (void)hipFree(c->d_counter);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return RT_OK;
+}
+
+const char *rt_last_error(rt_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int rt_resize(rt_ctx *c, int nx, int ny, int ns) {
+    if (!c) return RT_E_ARG;
+    if (nx <= 0 || ny <= 0 || ns <= 0) return fail(c, RT_E_ARG, "nx, ny, ns must be positive");
+    if ((long)nx * ny > (1L << 30)) return fail(c, RT_E_LIMIT, "frame too large (pixel index must fit int32)");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->nx = nx;
+    c->ny = ny;
+    c->ns = ns;
+    return ensure_fb(c);
+}
+
+int rt_set_scene(rt_ctx *c, const rt_triangle148 *tris, int n) {
+    if (!c) return RT_E_ARG;
+    if (!tris || n <= 0) return fail(c, RT_E_ARG, "empty scene");
+    if (tris[0].shapeType != 0)
+        return fail(c, RT_E_UNSUPPORTED,
+                    "tri[0] must be a triangle: it is the hard-coded light of pbrt_engine.cu:464,502 and a sphere there "
+                    "can make the zero-weighted pdf term NaN");
+    for (int i = 0; i < n; i++) {
+        if (tris[i].shapeType != 0 && tris[i].shapeType != 1)
+            return fail(c, RT_E_UNSUPPORTED, "shapeType must be 0 (triangle) or 1 (sphere)");
+        if (tris[i].shapeType == 0 && tris[i].texIdx != -1)
+            return fail(c, RT_E_UNSUPPORTED, "texIdx must be -1: the texture path is out of scope");
+        if (tris[i].matType < 0 || tris[i].matType >= RT_MAT_NUM) return fail(c, RT_E_ARG, "matType out of range");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    c->tris.assign(tris, tris + n);
+    c->bnodes.clear();
+    free_scene(c);
+    return RT_OK;
+}
+
+int rt_build_bvh(rt_ctx *c, int64_t rand_calls_before) {
+    if (!c) return RT_E_ARG;
+    if (c->tris.empty()) return fail(c, RT_E_ARG, "no scene");
+    if (rand_calls_before < 0) return fail(c, RT_E_ARG, "rand_calls_before < 0");
+    HIPCHK(c, hipSetDevice(c->device));
+    build_binary_bvh(c->tris.data(), (int)c->tris.size(), rand_calls_before, c->bnodes);
+    return upload_scene(c);
+}
+
+int rt_set_bvh_nodes(rt_ctx *c, const rt_bvh_node32 *nodes, int m) {
+    if (!c) return RT_E_ARG;
+    if (c->tris.empty()) return fail(c, RT_E_ARG, "no scene");
+    if (!nodes || m != 2 * (int)c->tris.size() - 1) return fail(c, RT_E_ARG, "node count must be 2*n-1");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->bnodes.assign(nodes, nodes + m);
+    int rc = upload_scene(c);
+    if (rc) c->bnodes.clear();
+    return rc;
+}
+
+int rt_get_bvh_nodes(rt_ctx *c, rt_bvh_node32 *out, int cap, int *m) {
+    if (!c || !m) return RT_E_ARG;
+    *m = (int)c->bnodes.size();
+    if (out) {
+        if (cap < *m) return fail(c, RT_E_ARG, "output too small");
+        std::memcpy(out, c->bnodes.data(), c->bnodes.size() * sizeof(rt_bvh_node32));
+    }
+    return RT_OK;
+}
+
+int rt_set_materials(rt_ctx *c, const rt_material *mats, int n) {
+    if (!c) return RT_E_ARG;
+    if (!mats || n <= 0 || n > RT_MAT_NUM) return fail(c, RT_E_ARG, "1..50 materials");
+    for (int i = 0; i < n; i++)
+        if (mats[i].kind < RT_MAT_LAMBERTIAN || mats[i].kind > RT_MAT_LIGHT) return fail(c, RT_E_ARG, "bad material kind");
+    std::memcpy(c->mats, mats, sizeof(rt_material) * (size_t)n);
+    c->mats_dirty = true;
+    return RT_OK;
+}
+
+int rt_set_camera(rt_ctx *c, const float lookfrom[3], const float lookat[3], float vfov, float dist_to_focus,
+                  float aperture) {
+    if (!c || !lookfrom || !lookat) return RT_E_ARG;
+    for (int k = 0; k < 3; k++) {
+        c->lookfrom[k] = lookfrom[k];
+        c->lookat[k] = lookat[k];
+    }
+    c->vfov = vfov;
+    c->focus = dist_to_focus;
+    c->aperture = aperture;
+    c->cam_set = true;
+    return RT_OK;
+}
+
+int rt_set_option(rt_ctx *c, int option, int64_t value) {
+    if (!c) return RT_E_ARG;
+    switch (option) {
+    case RT_OPT_MAX_DEPTH:
+        if (value < 1 || value > 1000000) return fail(c, RT_E_ARG, "max depth out of range");
+        c->max_depth = (int)value;
+        return RT_OK;
+    case RT_OPT_HONOR_VFOV:
+        c->honor_vfov = value ? 1 : 0;
+        return RT_OK;
+    case RT_OPT_LEAF_SIZE:
+        if (value < 1 || value > kMaxLeafPrims) return fail(c, RT_E_ARG, "leaf size 1..8");
+        if (c->leaf_size != (int)value) c->scene_on_device = false;
+        c->leaf_size = (int)value;
+        return RT_OK;
+    case RT_OPT_BOX_MODE:
+        if (value != 0 && value != 1) return fail(c, RT_E_ARG, "box mode 0 or 1");
+        if (c->box_mode != (int)value) c->scene_on_device = false;
+        c->box_mode = (int)value;
+        return RT_OK;
+    case RT_OPT_SHARD_RANK:
+        if (value < 0 || value >= c->shard_world) return fail(c, RT_E_ARG, "rank must be in [0, world)");
+        c->shard_rank = (int)value;
+        return RT_OK;
+    case RT_OPT_SHARD_WORLD:
+        if (value < 1 || value > 4096) return fail(c, RT_E_ARG, "world out of range");
+        c->shard_world = (int)value;
+        if (c->shard_rank >= c->shard_world) c->shard_rank = 0;
+        return RT_OK;
+    case RT_OPT_KERNEL:
+        c->kernel_variant = (int)value;
+        return RT_OK;
+    default:
+        return fail(c, RT_E_ARG, "unknown option");
+    }
+}
+
+int rt_get_option(rt_ctx *c, int option, int64_t *value) {
+    if (!c || !value) return RT_E_ARG;
+    switch (option) {
+    case RT_OPT_MAX_DEPTH: *value = c->max_depth; return RT_OK;
+    case RT_OPT_HONOR_VFOV: *value = c->honor_vfov; return RT_OK;
+    case RT_OPT_LEAF_SIZE: *value = c->leaf_size; return RT_OK;
+    case RT_OPT_BOX_MODE: *value = c->box_mode; return RT_OK;
+    case RT_OPT_SHARD_RANK: *value = c->shard_rank; return RT_OK;
+    case RT_OPT_SHARD_WORLD: *value = c->shard_world; return RT_OK;
+    case RT_OPT_KERNEL: *value = c->kernel_variant; return RT_OK;
+    default: return fail(c, RT_E_ARG, "unknown option");
+    }
+}
+
+static int render_into(rt_ctx *c, float *d_fb, rt_stats *st, double t0) {
+    KernelFrame F;
+    fill_frame(c, F);
+    HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
+    if (c->shard_world > 1) // pixels of other ranks' tiles read as 0, so that a sum over ranks assembles the frame
+        HIPCHK(c, hipMemsetAsync(d_fb, 0, (size_t)c->nx * c->ny * 3 * sizeof(float), c->stream));
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    HIPCHK(c, launch_render(scene_of(c), F, c->wide.stack_entries, d_fb, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0.0f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    unsigned long long rays = 0;
+    HIPCHK(c, hipMemcpy(&rays, c->d_counter, sizeof(rays), hipMemcpyDeviceToHost));
+    fill_stats(c, st, rays, ms, now_ms() - t0);
+    return RT_OK;
+}
+
+int rt_render_device(rt_ctx *c, float *fb_rgb_device, rt_stats *st) {
+    if (!c || !fb_rgb_device) return RT_E_ARG;
+    double t0 = now_ms();
+    if (!c->cam_set) return fail(c, RT_E_ARG, "no camera: call rt_set_camera first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ready_to_trace(c);
+    if (rc) return rc;
+    return render_into(c, fb_rgb_device, st, t0);
+}
+
+int rt_render(rt_ctx *c, float *fb_rgb_host, rt_stats *st) {
+    if (!c || !fb_rgb_host) return RT_E_ARG;
+    double t0 = now_ms();
+    if (!c->cam_set) return fail(c, RT_E_ARG, "no camera: call rt_set_camera first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ready_to_trace(c);
+    if (rc) return rc;
+    rc = ensure_fb(c);
+    if (rc) return rc;
+    rc = render_into(c, c->d_fb, st, t0);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(fb_rgb_host, c->d_fb, (size_t)c->nx * c->ny * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (st) st->total_ms = now_ms() - t0;
+    return RT_OK;
+}
+
+int rt_trace_primary(rt_ctx *c, int32_t *tri_id_host, float *t_host, rt_stats *st) {
+    if (!c || !tri_id_host || !t_host) return RT_E_ARG;
+    double t0 = now_ms();
+    if (!c->cam_set) return fail(c, RT_E_ARG, "no camera: call rt_set_camera first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ready_to_trace(c);
+    if (rc) return rc;
+    size_t px = (size_t)c->nx * c->ny;
+    int32_t *d_ids = nullptr;
+    float *d_ts = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_ids, px * sizeof(int32_t)));
+    if (hipMalloc((void **)&d_ts, px * sizeof(float)) != hipSuccess) {
+        (void)hipFree(d_ids);
+        return fail(c, RT_E_HIP, "hipMalloc failed");
+    }
+    auto cleanup = [&]() {
+        (void)hipFree(d_ids);
+        (void)hipFree(d_ts);
+    };
+    KernelFrame F;
+    fill_frame(c, F);
+    hipError_t e = hipSuccess;
+    float ms = 0.0f;
+    unsigned long long rays = 0;
+    do {
+        if ((e = hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream)) != hipSuccess) break;
+        if ((e = hipMemsetAsync(d_ids, 0xFF, px * sizeof(int32_t), c->stream)) != hipSuccess) break;
+        if ((e = hipMemsetAsync(d_ts, 0, px * sizeof(float), c->stream)) != hipSuccess) break;
+        if ((e = hipEventRecord(c->ev0, c->stream)) != hipSuccess) break;
+        if ((e = launch_trace_primary(scene_of(c), F, c->wide.stack_entries, d_ids, d_ts, c->stream)) != hipSuccess) break;
+        if ((e = hipEventRecord(c->ev1, c->stream)) != hipSuccess) break;
+        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) break;
+        if ((e = hipEventElapsedTime(&ms, c->ev0, c->ev1)) != hipSuccess) break;
+        if ((e = hipMemcpy(&rays, c->d_counter, sizeof(rays), hipMemcpyDeviceToHost)) != hipSuccess) break;
+        if ((e = hipMemcpy(tri_id_host, d_ids, px * sizeof(int32_t), hipMemcpyDeviceToHost)) != hipSuccess) break;
+        if ((e = hipMemcpy(t_host, d_ts, px * sizeof(float), hipMemcpyDeviceToHost)) != hipSuccess) break;
+    } while (0);
+    cleanup();
+    if (e != hipSuccess) return fail(c, RT_E_HIP, std::string("HIP error in rt_trace_primary: ") + hipGetErrorString(e));
+    fill_stats(c, st, rays, ms, now_ms() - t0);
+    return RT_OK;
+}
+
+int rt_trace_rays(rt_ctx *c, const float *org_dir6, int n_rays, int32_t *tri_id_host, float *t_host, rt_stats *st) {
+    if (!c || !org_dir6 || !tri_id_host || !t_host || n_rays <= 0) return RT_E_ARG;
+    double t0 = now_ms();
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ready_to_trace(c);
+    if (rc) return rc;
+    float *d_rays = nullptr, *d_ts = nullptr;
+    int32_t *d_ids = nullptr;
+    hipError_t e = hipSuccess;
+    float ms = 0.0f;
+    unsigned long long rays = 0;
+    do {
+        if ((e = hipMalloc((void **)&d_rays, (size_t)n_rays * 6 * sizeof(float))) != hipSuccess) break;
+        if ((e = hipMalloc((void **)&d_ids, (size_t)n_rays * sizeof(int32_t))) != hipSuccess) break;
+        if ((e = hipMalloc((void **)&d_ts, (size_t)n_rays * sizeof(float))) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d_rays, org_dir6, (size_t)n_rays * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream)) !=
+            hipSuccess)
+            break;
+        if ((e = hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream)) != hipSuccess) break;
+        if ((e = hipEventRecord(c->ev0, c->stream)) != hipSuccess) break;
+        if ((e = launch_trace_rays(scene_of(c), c->wide.stack_entries, d_rays, n_rays, d_ids, d_ts, c->d_counter,
+                                   c->stream)) != hipSuccess)
+            break;
+        if ((e = hipEventRecord(c->ev1, c->stream)) != hipSuccess) break;
+        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) break;
+        if ((e = hipEventElapsedTime(&ms, c->ev0, c->ev1)) != hipSuccess) break;
+        if ((e = hipMemcpy(&rays, c->d_counter, sizeof(rays), hipMemcpyDeviceToHost)) != hipSuccess) break;
+        if ((e = hipMemcpy(tri_id_host, d_ids, (size_t)n_rays * sizeof(int32_t), hipMemcpyDeviceToHost)) != hipSuccess) break;
+        if ((e = hipMemcpy(t_host, d_ts, (size_t)n_rays * sizeof(float), hipMemcpyDeviceToHost)) != hipSuccess) break;
+    } while (0);
+    if (d_rays) (void)hipFree(d_rays);
+    if (d_ids) (void)hipFree(d_ids);
+    if (d_ts) (void)hipFree(d_ts);
+    if (e != hipSuccess) return fail(c, RT_E_HIP, std::string("HIP error in rt_trace_rays: ") + hipGetErrorString(e));
+    fill_stats(c, st, rays, ms, now_ms() - t0);
+    return RT_OK;
+}
+
+int rt_write_ppm(const char *path, const float *fb, int nx, int ny) {
+    if (!path || !fb || nx <= 0 || ny <= 0) return RT_E_ARG;
+    FILE *f = std::fopen(path, "w");
+    if (!f) return RT_E_ARG;
+    std::fprintf(f, "P3\n%d %d\n255\n", nx, ny);
+    for (int j = ny - 1; j >= 0; j--) {
+        for (int i = 0; i < nx; i++) {
+            size_t p = 3 * ((size_t)j * nx + i);
+            int ir = int(255.99 * fb[p + 0]);
+            int ig = int(255.99 * fb[p + 1]);
+            int ib = int(255.99 * fb[p + 2]);
+            std::fprintf(f, "%d %d %d\n", ir, ig, ib);
+        }
+    }
+    return std::fclose(f) == 0 ? RT_OK : RT_E_ARG;
+}
+
+int rt_test_glibc_rand(uint32_t seed, int n, int32_t *out) {
+    if (!out || n < 0) return RT_E_ARG;
+    GlibcRand g(seed);
+    for (int i = 0; i < n; i++) out[i] = g.next();
+    return RT_OK;
+}
+
+int rt_test_introsort(const float *key, int32_t *idx, int n) {
+    if (!key || !idx || n < 0) return RT_E_ARG;
+    introsort_by_key(key, idx, n);
+    return RT_OK;
+}
+
+int rt_test_build_bvh(const rt_triangle148 *tris, int n, int64_t rand_calls_before, rt_bvh_node32 *out) {
+    if (!tris || !out || n <= 0 || rand_calls_before < 0) return RT_E_ARG;
+    std::vector<rt_bvh_node32> nodes;
+    build_binary_bvh(tris, n, rand_calls_before, nodes);
+    std::memcpy(out, nodes.data(), nodes.size() * sizeof(rt_bvh_node32));
+    return RT_OK;
+}
+
+int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size,
+                        int box_mode, void *wide_nodes, void *prims, int32_t info[4]) {
+    if (!tris || !nodes || !info) return RT_E_ARG;
+    WideBvh w;
+    std::string err;
+    if (!build_wide_bvh(tris, n, nodes, m, leaf_size, box_mode, w, err)) return RT_E_ARG;
+    info[0] = (int32_t)w.nodes.size();
+    info[1] = (int32_t)w.prims.size();
+    info[2] = w.depth;
+    info[3] = w.stack_entries;
+    if (wide_nodes) std::memcpy(wide_nodes, w.nodes.data(), w.nodes.size() * sizeof(WideNode));
+    if (prims) std::memcpy(prims, w.prims.data(), w.prims.size() * sizeof(DevPrim));
+    return RT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,59 @@
+// rt_types.h -- device data layout shared by the host builders and the HIP kernels.
+#pragma once
+#include <cstdint>
+
+namespace rtamd {
+
+// ---- wide BVH node: 4 children, 128 bytes, one L2 line, 128-byte aligned ----
+// SoA inside the node so that one 16-byte load brings the same plane of all 4 children:
+//   plane[0..2] = min x/y/z of children 0..3, plane[3..5] = max x/y/z,
+//   child[4]    = reference per child (see below), aux[4] unused (keeps the node one line).
+// A ray picks its near/far plane vectors by direction sign, so no per-child select is needed.
+struct WideNode {
+    float plane[6][4];
+    uint32_t child[4];
+    uint32_t aux[4];
+};
+static_assert(sizeof(WideNode) == 128, "WideNode must be one 128-byte line");
+
+// child reference encoding
+constexpr uint32_t kLeafBit = 0x80000000u;  // leaf: bits 0..27 first primitive (DFS rank), bits 28..30 count-1
+constexpr uint32_t kEmptyRef = 0xFFFFFFFFu; // unused slot (its box is inverted and can never be hit)
+constexpr uint32_t kLeafStartMask = 0x0FFFFFFFu;
+constexpr int kMaxLeafPrims = 8;
+
+// ---- primitive record used by the intersection test: 48 bytes, in DFS leaf order ----
+// (so that "earlier DFS leaf wins a tie", reference pbrt_engine.cu:421-438, is "lower index wins")
+//   a = (v0.x, v0.y, v0.z, e1.x)      sphere: centre, radius
+//   b = (e1.y, e1.z, e2.x, e2.y)
+//   c = (e2.z, shape (0 tri / 1 sphere), original index, material)
+struct DevPrim {
+    float a[4];
+    float b[4];
+    float e2z;
+    int32_t shape;
+    int32_t orig;
+    int32_t mat;
+};
+static_assert(sizeof(DevPrim) == 48, "DevPrim must be 48 bytes");
+
+// ---- shading record fetched once per hit: 16 bytes, same order ----
+struct DevShade {
+    float normal[3];
+    int32_t mat;
+};
+
+// ---- material, camera: small PODs kept in kernel-argument / constant space ----
+struct DevMat {
+    int32_t kind;
+    float albedo[3];
+    float param;
+};
+
+struct DevCamera { // reference camera object, include/RT/rt_camera.h:62-69
+    float origin[3], lower_left[3], horizontal[3], vertical[3];
+    float u[3], v[3], w[3];
+    float lens_radius, time0, time1;
+};
+
+} // namespace rtamd

@@ -1,0 +1,223 @@
+// wide_bvh.cpp -- see wide_bvh.h.
+#include "wide_bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "bvh_build.h"
+
+namespace rtamd {
+
+namespace {
+
+struct Info {
+    float mn[3], mx[3]; // tight bounds of the subtree
+    int32_t first;      // DFS rank of the first primitive below
+    int32_t count;      // primitives below
+};
+
+inline float half_area(const Info &b) {
+    float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+} // namespace
+
+bool build_wide_bvh(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size, int box_mode,
+                    WideBvh &out, std::string &err) {
+    out = WideBvh();
+    if (n <= 0 || m <= 0) {
+        err = "empty scene";
+        return false;
+    }
+    if (m != 2 * n - 1) {
+        err = "node count must be 2*n-1";
+        return false;
+    }
+    if ((unsigned)n > kLeafStartMask) {
+        err = "too many primitives for the 28-bit leaf reference";
+        return false;
+    }
+    leaf_size = std::max(1, std::min(leaf_size, kMaxLeafPrims));
+
+    // ---- pass 1: DFS from the root; rank leaves, collect per-subtree info, validate the tree ----
+    std::vector<Info> info(m);
+    std::vector<uint8_t> seen(m, 0);
+    std::vector<int32_t> order; // order[rank] = primitive index
+    order.reserve(n);
+    std::vector<uint8_t> prim_seen(n, 0);
+    struct Frame {
+        int32_t node;
+        int32_t phase;
+    };
+    std::vector<Frame> stk;
+    stk.push_back({m - 1, 0});
+    while (!stk.empty()) {
+        Frame f = stk.back();
+        stk.pop_back();
+        const rt_bvh_node32 &nd = nodes[f.node];
+        Info &I = info[f.node];
+        if (f.phase == 0) {
+            if (seen[f.node]) {
+                err = "node reached twice: not a tree";
+                return false;
+            }
+            seen[f.node] = 1;
+            I.first = (int32_t)order.size();
+            if (nd.left == nd.right) {
+                if (nd.left < 0 || nd.left >= n || prim_seen[nd.left]) {
+                    err = "leaf primitive index out of range or repeated";
+                    return false;
+                }
+                prim_seen[nd.left] = 1;
+                order.push_back(nd.left);
+                I.count = 1;
+                prim_box_tight(tris[nd.left], I.mn, I.mx);
+            } else {
+                if (nd.left < 0 || nd.left >= m || nd.right < 0 || nd.right >= m) {
+                    err = "child index out of range";
+                    return false;
+                }
+                stk.push_back({f.node, 1});
+                stk.push_back({nd.right, 0});
+                stk.push_back({nd.left, 0});
+            }
+        } else {
+            const Info &L = info[nd.left], &R = info[nd.right];
+            I.count = L.count + R.count;
+            for (int a = 0; a < 3; a++) {
+                I.mn[a] = std::min(L.mn[a], R.mn[a]);
+                I.mx[a] = std::max(L.mx[a], R.mx[a]);
+            }
+        }
+    }
+    if ((int)order.size() != n) {
+        err = "tree does not cover every primitive";
+        return false;
+    }
+
+    // ---- primitives in DFS leaf order ----
+    out.prims.resize(n);
+    out.shade.resize(n);
+    for (int r = 0; r < n; r++) {
+        const rt_triangle148 &t = tris[order[r]];
+        DevPrim &p = out.prims[r];
+        DevShade &s = out.shade[r];
+        if (t.shapeType == 0) {
+            p.a[0] = t.v0[0]; p.a[1] = t.v0[1]; p.a[2] = t.v0[2]; p.a[3] = t.edge1[0];
+            p.b[0] = t.edge1[1]; p.b[1] = t.edge1[2]; p.b[2] = t.edge2[0]; p.b[3] = t.edge2[1];
+            p.e2z = t.edge2[2];
+            p.shape = 0;
+            s.normal[0] = t.normal[0]; s.normal[1] = t.normal[1]; s.normal[2] = t.normal[2];
+        } else {
+            p.a[0] = t.v0[0]; p.a[1] = t.v0[1]; p.a[2] = t.v0[2]; p.a[3] = t.v1[0];
+            p.b[0] = p.b[1] = p.b[2] = p.b[3] = 0.0f;
+            p.e2z = 0.0f;
+            p.shape = 1;
+            s.normal[0] = s.normal[1] = s.normal[2] = 0.0f;
+        }
+        p.orig = order[r];
+        p.mat = t.matType;
+        s.mat = t.matType;
+    }
+
+    // ---- pad for re-fitted boxes: 2^-17 of the largest |coordinate| of the scene ----
+    float extent = 0.0f;
+    {
+        const Info &R = info[m - 1];
+        for (int a = 0; a < 3; a++) extent = std::max(extent, std::max(std::fabs(R.mn[a]), std::fabs(R.mx[a])));
+    }
+    out.pad = std::ldexp(extent > 1.0f ? extent : 1.0f, -17);
+
+    auto write_box = [&](WideNode &w, int slot, int32_t bnode) {
+        if (box_mode == 1) {
+            const rt_bvh_node32 &nd = nodes[bnode];
+            for (int a = 0; a < 3; a++) {
+                w.plane[a][slot] = nd.box_min[a];
+                w.plane[3 + a][slot] = nd.box_max[a];
+            }
+        } else {
+            const Info &I = info[bnode];
+            for (int a = 0; a < 3; a++) {
+                w.plane[a][slot] = I.mn[a] - out.pad;
+                w.plane[3 + a][slot] = I.mx[a] + out.pad;
+            }
+        }
+    };
+
+    // ---- pass 2: breadth-first collapse, largest half-area first ----
+    struct Work {
+        int32_t bnode; // binary subtree to expand into this wide node
+        int32_t wnode;
+        int32_t level;
+    };
+    std::vector<Work> queue;
+    out.nodes.reserve((size_t)n / 2 + 16);
+    out.nodes.emplace_back();
+    queue.push_back({m - 1, 0, 1});
+    int max_level = 1;
+    for (size_t qi = 0; qi < queue.size(); qi++) {
+        Work wk = queue[qi];
+        max_level = std::max(max_level, wk.level);
+        int32_t slots[4];
+        int ns = 0;
+        const rt_bvh_node32 &b = nodes[wk.bnode];
+        if (info[wk.bnode].count <= leaf_size || b.left == b.right) {
+            slots[ns++] = wk.bnode; // whole (sub)scene fits one leaf: a node with a single leaf child
+        } else {
+            slots[ns++] = b.left;
+            slots[ns++] = b.right;
+            while (ns < 4) {
+                int pick = -1;
+                float best = -1.0f;
+                for (int s = 0; s < ns; s++) {
+                    const rt_bvh_node32 &c = nodes[slots[s]];
+                    if (c.left == c.right || info[slots[s]].count <= leaf_size) continue;
+                    float a = half_area(info[slots[s]]);
+                    if (a > best) {
+                        best = a;
+                        pick = s;
+                    }
+                }
+                if (pick < 0) break;
+                const rt_bvh_node32 &c = nodes[slots[pick]];
+                // keep DFS order among the slots: left child takes the slot, right child goes right after it
+                for (int s = ns; s > pick + 1; s--) slots[s] = slots[s - 1];
+                slots[pick] = c.left;
+                slots[pick + 1] = c.right;
+                ns++;
+            }
+        }
+        WideNode w;
+        std::memset(&w, 0, sizeof(w));
+        for (int s = 0; s < 4; s++) {
+            if (s < ns) {
+                const Info &I = info[slots[s]];
+                const rt_bvh_node32 &c = nodes[slots[s]];
+                write_box(w, s, slots[s]);
+                if (c.left == c.right || I.count <= leaf_size) {
+                    w.child[s] = kLeafBit | ((uint32_t)(I.count - 1) << 28) | (uint32_t)I.first;
+                } else {
+                    int32_t idx = (int32_t)out.nodes.size();
+                    out.nodes.emplace_back();
+                    w.child[s] = (uint32_t)idx;
+                    queue.push_back({slots[s], idx, wk.level + 1});
+                }
+            } else {
+                for (int a = 0; a < 3; a++) {
+                    w.plane[a][s] = std::numeric_limits<float>::infinity();
+                    w.plane[3 + a][s] = -std::numeric_limits<float>::infinity();
+                }
+                w.child[s] = kEmptyRef;
+            }
+        }
+        out.nodes[wk.wnode] = w;
+    }
+    out.depth = max_level;
+    out.stack_entries = 3 * max_level + 2;
+    return true;
+}
+
+} // namespace rtamd

@@ -1,0 +1,28 @@
+// wide_bvh.h -- turns the reference's binary BVH (post-order rt_bvh_node32 array, root last) into the
+// device layout of rt_types.h: 4-wide, 128-byte nodes in breadth-first order, primitives re-ordered
+// into DFS leaf order.  The TOPOLOGY is the reference's (each wide node is a 2-level cut of the
+// binary tree, chosen largest-surface-area-first); only boxes and packing are device-specific.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/rt_abi.h"
+#include "rt_types.h"
+
+namespace rtamd {
+
+struct WideBvh {
+    std::vector<WideNode> nodes; // nodes[0] is the root
+    std::vector<DevPrim> prims;  // DFS leaf order of the binary tree
+    std::vector<DevShade> shade; // same order
+    int depth = 0;               // wide levels below the root node (root = 1)
+    int stack_entries = 0;       // worst-case traversal stack entries per ray
+    float pad = 0.0f;            // box pad actually applied (box_mode 0)
+};
+
+// leaf_size: 1..kMaxLeafPrims primitives per leaf.  box_mode: 0 = re-fitted + one pad, 1 = reference boxes.
+// Returns false and fills err if the node array is not a tree over exactly the n primitives.
+bool build_wide_bvh(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size, int box_mode,
+                    WideBvh &out, std::string &err);
+
+} // namespace rtamd

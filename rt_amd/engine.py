@@ -1,0 +1,302 @@
+"""ctypes binding of include/rt_abi.h and a PbrtEngine mirror.
+
+Reference surface mirrored (include/RT/pbrt_engine.h:51-203, src/pbrt/pbrt_engine.cu:65-236):
+``setNx/setNy/setNs``, ``uponPixelNumChange``, ``renderScene``, plus the pieces the reference keeps in
+other classes and that feed the kernel: the triangle list (``m_vecTriangles``), the camera values read
+at pbrt_engine.cu:104-106, and the material table of material_init (:25-47).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+
+# reference Triangle, include/RT/triangle.h:345-354 (148 bytes)
+TRI_DTYPE = np.dtype(
+    [
+        ("v0", "<f4", 3), ("v1", "<f4", 3), ("v2", "<f4", 3),
+        ("normal", "<f4", 3),
+        ("edge1", "<f4", 3), ("edge2", "<f4", 3),
+        ("u", "<f4", 3), ("v", "<f4", 3),
+        ("n0", "<f4", 3), ("n1", "<f4", 3), ("n2", "<f4", 3),
+        ("calNormal", "<i4"), ("matType", "<i4"), ("shapeType", "<i4"), ("texIdx", "<i4"),
+    ]
+)
+assert TRI_DTYPE.itemsize == 148
+# reference bvh_node, include/RT/triangle.h:364-391 (32 bytes)
+NODE_DTYPE = np.dtype([("box_min", "<f4", 3), ("box_max", "<f4", 3), ("left", "<i4"), ("right", "<i4")])
+assert NODE_DTYPE.itemsize == 32
+MAT_DTYPE = np.dtype([("kind", "<i4"), ("albedo", "<f4", 3), ("param", "<f4")])
+assert MAT_DTYPE.itemsize == 20
+
+MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_LIGHT = 0, 1, 2, 3
+OPT_MAX_DEPTH, OPT_HONOR_VFOV, OPT_LEAF_SIZE, OPT_BOX_MODE, OPT_SHARD_RANK, OPT_SHARD_WORLD, OPT_KERNEL = 1, 2, 3, 4, 5, 6, 7
+
+
+class RtStats(C.Structure):
+    _fields_ = [
+        ("rays", C.c_uint64),
+        ("kernel_ms", C.c_double),
+        ("total_ms", C.c_double),
+        ("wide_nodes", C.c_uint64),
+        ("prims", C.c_uint64),
+        ("stack_entries", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class RtError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# every symbol include/rt_abi.h declares
+ABI_SYMBOLS = [
+    "rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_resize", "rt_set_scene", "rt_build_bvh",
+    "rt_set_bvh_nodes", "rt_get_bvh_nodes", "rt_default_materials", "rt_set_materials", "rt_set_camera",
+    "rt_set_option", "rt_get_option", "rt_render", "rt_render_device", "rt_trace_primary", "rt_trace_rays",
+    "rt_write_ppm", "rt_test_glibc_rand", "rt_test_introsort", "rt_test_build_bvh", "rt_test_wide_layout",
+]
+
+
+def load_library(path: str = LIB_PATH):
+    """Load librt_amd.so.  Raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RtError(f"{path} is missing: build it with `make -C rt_amd/csrc` (there is no CPU fallback)")
+    lib = C.CDLL(path)
+    vp, ip, fp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    lib.rt_abi_version.restype = C.c_int
+    lib.rt_create.argtypes = [C.POINTER(vp), C.c_int]
+    lib.rt_destroy.argtypes = [vp]
+    lib.rt_last_error.argtypes = [vp]
+    lib.rt_last_error.restype = C.c_char_p
+    lib.rt_resize.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    lib.rt_set_scene.argtypes = [vp, vp, C.c_int]
+    lib.rt_build_bvh.argtypes = [vp, C.c_int64]
+    lib.rt_set_bvh_nodes.argtypes = [vp, vp, C.c_int]
+    lib.rt_get_bvh_nodes.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
+    lib.rt_default_materials.argtypes = [vp]
+    lib.rt_set_materials.argtypes = [vp, vp, C.c_int]
+    lib.rt_set_camera.argtypes = [vp, fp, fp, C.c_float, C.c_float, C.c_float]
+    lib.rt_set_option.argtypes = [vp, C.c_int, C.c_int64]
+    lib.rt_get_option.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
+    lib.rt_render.argtypes = [vp, vp, C.POINTER(RtStats)]
+    lib.rt_render_device.argtypes = [vp, vp, C.POINTER(RtStats)]
+    lib.rt_trace_primary.argtypes = [vp, vp, vp, C.POINTER(RtStats)]
+    lib.rt_trace_rays.argtypes = [vp, vp, C.c_int, vp, vp, C.POINTER(RtStats)]
+    lib.rt_write_ppm.argtypes = [C.c_char_p, vp, C.c_int, C.c_int]
+    lib.rt_test_glibc_rand.argtypes = [C.c_uint32, C.c_int, vp]
+    lib.rt_test_introsort.argtypes = [vp, vp, C.c_int]
+    lib.rt_test_build_bvh.argtypes = [vp, C.c_int, C.c_int64, vp]
+    lib.rt_test_wide_layout.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    for name in ABI_SYMBOLS:
+        if name != "rt_last_error":
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_materials() -> np.ndarray:
+    """material_init + rand_init (pbrt_engine.cu:25-47,597-601) as a 50-entry table."""
+    lib = load_library()
+    out = np.zeros(50, dtype=MAT_DTYPE)
+    rc = lib.rt_default_materials(_ptr(out))
+    if rc:
+        raise RtError(f"rt_default_materials failed ({rc})")
+    return out
+
+
+def host_build_bvh(tris: np.ndarray, rand_calls_before: int = 0) -> np.ndarray:
+    """The bit-exact host builder alone (make_bvh_nodes, pbrt_engine.cu:335-368); needs no GPU."""
+    lib = load_library()
+    tris = np.ascontiguousarray(tris, dtype=TRI_DTYPE)
+    out = np.zeros(2 * tris.shape[0] - 1, dtype=NODE_DTYPE)
+    rc = lib.rt_test_build_bvh(_ptr(tris), tris.shape[0], rand_calls_before, _ptr(out))
+    if rc:
+        raise RtError(f"rt_test_build_bvh failed ({rc})")
+    return out
+
+
+WIDE_DTYPE = np.dtype([("plane", "<f4", (6, 4)), ("child", "<u4", 4), ("aux", "<u4", 4)])
+PRIM_DTYPE = np.dtype([("a", "<f4", 4), ("b", "<f4", 4), ("e2z", "<f4"), ("shape", "<i4"), ("orig", "<i4"), ("mat", "<i4")])
+
+
+def host_wide_layout(tris: np.ndarray, nodes: np.ndarray, leaf_size: int = 4, box_mode: int = 0):
+    """The device layout alone (wide nodes, re-ordered primitives, depth, stack entries); needs no GPU."""
+    lib = load_library()
+    tris = np.ascontiguousarray(tris, dtype=TRI_DTYPE)
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    info = np.zeros(4, dtype=np.int32)
+    rc = lib.rt_test_wide_layout(_ptr(tris), tris.shape[0], _ptr(nodes), nodes.shape[0], leaf_size, box_mode, None, None,
+                                 _ptr(info))
+    if rc:
+        raise RtError(f"rt_test_wide_layout failed ({rc})")
+    wide = np.zeros(int(info[0]), dtype=WIDE_DTYPE)
+    prims = np.zeros(int(info[1]), dtype=PRIM_DTYPE)
+    rc = lib.rt_test_wide_layout(_ptr(tris), tris.shape[0], _ptr(nodes), nodes.shape[0], leaf_size, box_mode, _ptr(wide),
+                                 _ptr(prims), _ptr(info))
+    if rc:
+        raise RtError(f"rt_test_wide_layout failed ({rc})")
+    return wide, prims, int(info[2]), int(info[3])
+
+
+def write_ppm(path: str, fb: np.ndarray) -> None:
+    """PPM writer of __renderScene (pbrt_engine.cu:123-133).  fb: (ny, nx, 3) float32, row 0 = bottom."""
+    lib = load_library()
+    fb = np.ascontiguousarray(fb, dtype=np.float32)
+    ny, nx = fb.shape[0], fb.shape[1]
+    rc = lib.rt_write_ppm(path.encode(), _ptr(fb), nx, ny)
+    if rc:
+        raise RtError(f"rt_write_ppm failed ({rc})")
+
+
+class PbrtEngine:
+    """Mirror of the reference's PbrtEngine over the C ABI.  One engine drives one GPU."""
+
+    def __init__(self, nx: int = 1280 // 2, ny: int = 720 // 2, ns: int = 100 // 10, device: int = 0):
+        # NX/NY/NS, include/RT/pbrt_engine.h:24-26
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.rt_create(C.byref(self._h), device)
+        if rc:
+            self._h = C.c_void_p()
+            raise RtError(f"rt_create failed ({rc}): no usable HIP device {device}; there is no CPU fallback")
+        self.nx, self.ny, self.ns = nx, ny, ns
+        self.tx = self.ty = 16  # printed only; the launch geometry is the library's (8x8 tiles, 64-lane waves)
+        self.nx_ny_changed = False
+        self.last_stats = RtStats()
+        self.uponPixelNumChange()
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.rt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc:
+            msg = self._lib.rt_last_error(self._h)
+            raise RtError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    # -- reference setters (pbrt_engine.h:65-91) ------------------------------------------
+    def setNx(self, nx: int):
+        if nx != self.nx:
+            self.nx_ny_changed = True
+        self.nx = nx
+
+    def setNy(self, ny: int):
+        if ny != self.ny:
+            self.nx_ny_changed = True
+        self.ny = ny
+
+    def setNs(self, ns: int):
+        self.ns = ns
+
+    def uponPixelNumChange(self):
+        self._check(self._lib.rt_resize(self._h, self.nx, self.ny, self.ns), "rt_resize")
+
+    # -- scene ------------------------------------------------------------------------------
+    def setTriangles(self, tris: np.ndarray):
+        """m_vecTriangles (light first), as produced by Mesh::genTriangles."""
+        tris = np.ascontiguousarray(tris, dtype=TRI_DTYPE)
+        self._check(self._lib.rt_set_scene(self._h, _ptr(tris), int(tris.shape[0])), "rt_set_scene")
+        self.num_triangles = int(tris.shape[0])
+
+    def buildBvh(self, rand_calls_before: int = 0):
+        self._check(self._lib.rt_build_bvh(self._h, rand_calls_before), "rt_build_bvh")
+
+    def setBvhNodes(self, nodes: np.ndarray):
+        nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+        self._check(self._lib.rt_set_bvh_nodes(self._h, _ptr(nodes), int(nodes.shape[0])), "rt_set_bvh_nodes")
+
+    def getBvhNodes(self) -> np.ndarray:
+        m = C.c_int(0)
+        self._check(self._lib.rt_get_bvh_nodes(self._h, None, 0, C.byref(m)), "rt_get_bvh_nodes")
+        out = np.zeros(m.value, dtype=NODE_DTYPE)
+        self._check(self._lib.rt_get_bvh_nodes(self._h, _ptr(out), m.value, C.byref(m)), "rt_get_bvh_nodes")
+        return out
+
+    def setMaterials(self, mats: np.ndarray):
+        mats = np.ascontiguousarray(mats, dtype=MAT_DTYPE)
+        self._check(self._lib.rt_set_materials(self._h, _ptr(mats), int(mats.shape[0])), "rt_set_materials")
+
+    def setCamera(self, lookfrom, lookat, vfov: float = 40.0, dist_to_focus: float = 10.0, aperture: float = 0.0):
+        a = (C.c_float * 3)(*[float(x) for x in lookfrom])
+        b = (C.c_float * 3)(*[float(x) for x in lookat])
+        self._check(self._lib.rt_set_camera(self._h, a, b, vfov, dist_to_focus, aperture), "rt_set_camera")
+
+    def setOption(self, opt: int, value: int):
+        self._check(self._lib.rt_set_option(self._h, opt, int(value)), "rt_set_option")
+
+    def setMaxDepth(self, d: int):
+        self.setOption(OPT_MAX_DEPTH, d)
+
+    def setShard(self, rank: int, world: int):
+        self.setOption(OPT_SHARD_WORLD, world)
+        self.setOption(OPT_SHARD_RANK, rank)
+
+    # -- render -----------------------------------------------------------------------------
+    def render(self) -> np.ndarray:
+        """render<<<>>> + sync + D2H.  Returns (ny, nx, 3) float32, row 0 = bottom row."""
+        self.uponPixelNumChange()
+        fb = np.zeros((self.ny, self.nx, 3), dtype=np.float32)
+        self._check(self._lib.rt_render(self._h, _ptr(fb), C.byref(self.last_stats)), "rt_render")
+        return fb
+
+    def renderDevice(self, device_ptr: int) -> RtStats:
+        """Same, into caller-owned device memory (e.g. a torch tensor's data_ptr())."""
+        self._check(self._lib.rt_render_device(self._h, C.c_void_p(device_ptr), C.byref(self.last_stats)),
+                    "rt_render_device")
+        return self.last_stats
+
+    def tracePrimary(self):
+        self.uponPixelNumChange()
+        ids = np.zeros((self.ny, self.nx), dtype=np.int32)
+        ts = np.zeros((self.ny, self.nx), dtype=np.float32)
+        self._check(self._lib.rt_trace_primary(self._h, _ptr(ids), _ptr(ts), C.byref(self.last_stats)),
+                    "rt_trace_primary")
+        return ids, ts
+
+    def traceRays(self, org_dir6: np.ndarray):
+        rays = np.ascontiguousarray(org_dir6, dtype=np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        ids = np.zeros(n, dtype=np.int32)
+        ts = np.zeros(n, dtype=np.float32)
+        self._check(self._lib.rt_trace_rays(self._h, _ptr(rays), n, _ptr(ids), _ptr(ts), C.byref(self.last_stats)),
+                    "rt_trace_rays")
+        return ids, ts
+
+    def renderScene(self, _buildScene: bool = True, out_path: str = "./output.ppm", file=sys.stdout) -> np.ndarray:
+        """renderScene + __renderScene + join (pbrt_engine.cu:89-157): same stdout lines, same PPM bytes."""
+        print(f"rendering a {self.nx}[width]x{self.ny}[height] image with {self.ns} samples per pixel in "
+              f"{self.tx}x{self.ty} blocks.", file=file)
+        if _buildScene:
+            print("INFO: generate scene.", file=file)
+            print(f"Total num of Triangles: {self.num_triangles}", file=file)
+            self.buildBvh()
+        else:
+            print("INFO: using scene generated.", file=file)
+        fb = self.render()
+        print(f"took {self.last_stats.kernel_ms / 1000.0:g} seconds.", file=file)
+        write_ppm(out_path, fb)
+        print("PbrtEngine: rendering finished.", file=file)
+        return fb

@@ -1,0 +1,216 @@
+"""CPU tests of the product's host side (no GPU needed): the C-ABI library loads and exports every symbol
+include/rt_abi.h declares; the restated glibc rand() and libstdc++ std::sort match the real ones; the
+bit-exact host BVH builder matches the oracle's (which uses rand()/std::sort directly, as the reference
+does, pbrt_engine.cu:335-368); the wide device layout covers every primitive and returns the oracle's hits
+when traversed by a plain Python loop."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from rt_amd import engine, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    lib = engine.load_library()
+    hdr = open(os.path.join(ROOT, "include", "rt_abi.h")).read()
+    declared = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in rt_abi.h but not exported"
+    assert declared == set(engine.ABI_SYMBOLS)
+    assert lib.rt_abi_version() == 1
+
+
+def test_struct_sizes():
+    assert engine.TRI_DTYPE.itemsize == 148
+    assert engine.NODE_DTYPE.itemsize == 32
+    assert engine.WIDE_DTYPE.itemsize == 128
+    assert engine.PRIM_DTYPE.itemsize == 48
+
+
+def test_glibc_rand_restatement(oracle):
+    lib = engine.load_library()
+    for seed in (1, 2, 12345, 0):
+        want = oracle.libc_rand(seed, 5000)
+        got = np.zeros(5000, dtype=np.int32)
+        assert lib.rt_test_glibc_rand(seed, 5000, engine._ptr(got)) == 0
+        assert (want == got).all()
+    assert oracle.libc_rand(1, 1)[0] == 1804289383
+
+
+def _keys(kind, n, rs):
+    if kind == "random":
+        return rs.rand(n).astype(np.float32)
+    if kind == "ties":
+        return rs.randint(0, max(2, n // 50), n).astype(np.float32)
+    if kind == "sorted":
+        return np.arange(n, dtype=np.float32)
+    if kind == "reverse":
+        return np.arange(n, 0, -1).astype(np.float32)
+    if kind == "equal":
+        return np.zeros(n, dtype=np.float32)
+    if kind == "organ":
+        h = n // 2
+        return np.concatenate([np.arange(h), np.arange(n - h, 0, -1)]).astype(np.float32)
+    if kind == "killer":  # median-of-3 killer: drives introsort into its heapsort fallback
+        k = n // 2
+        a = np.zeros(2 * k, dtype=np.float32)
+        for i in range(k):
+            if i % 2 == 0:
+                a[i] = i + 1
+            else:
+                a[i] = k + i + (k % 2 == 0)
+            a[k + i] = 2 * (i + 1)
+        return a
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["random", "ties", "sorted", "reverse", "equal", "organ", "killer"])
+def test_introsort_restatement(oracle, kind):
+    lib = engine.load_library()
+    rs = np.random.RandomState(11)
+    for n in (0, 1, 2, 3, 15, 16, 17, 33, 100, 1000, 4096, 50001):
+        key = _keys(kind, n, rs)
+        n = key.shape[0]
+        idx = np.arange(n, dtype=np.int32)
+        assert lib.rt_test_introsort(engine._ptr(key), engine._ptr(idx), n) == 0
+        assert (idx == oracle.std_sort(key)).all(), (kind, n)
+
+
+@pytest.mark.parametrize("scene", ["hf5", "hf40", "hf224", "spheres"])
+def test_host_builder_bit_exact(oracle, scene):
+    tris = {"hf5": lambda: scenes.heightfield(5), "hf40": lambda: scenes.heightfield(40),
+            "hf224": lambda: scenes.heightfield(224), "spheres": scenes.spheres_scene}[scene]()
+    want = oracle.build_bvh(tris)
+    got = engine.host_build_bvh(tris)
+    assert want.tobytes() == got.tobytes()
+
+
+def test_host_builder_tiny_and_offset(oracle):
+    tris = scenes.light_quad()
+    assert engine.host_build_bvh(tris).tobytes() == oracle.build_bvh(tris).tobytes()
+    one = tris[:1]
+    assert engine.host_build_bvh(one).shape[0] == 1
+    # a different number of preceding rand() calls changes the axis sequence (main.cpp:449-474 shares rand())
+    t = scenes.heightfield(9)
+    assert engine.host_build_bvh(t, 0).tobytes() != engine.host_build_bvh(t, 5).tobytes()
+
+
+def _py_closest(wide, prims, org, d):
+    """Plain-Python traversal of the wide layout (float64 boxes, float32-faithful primitive test is the
+    oracle's job; here ids only)."""
+    best_t, best = np.inf, -1
+    stack = [0]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / d.astype(np.float64)
+    while stack:
+        cur = stack.pop()
+        if cur & 0x80000000:
+            start, cnt = cur & 0x0FFFFFFF, ((cur >> 28) & 7) + 1
+            for r in range(start, start + cnt):
+                p = prims[r]
+                if p["shape"] == 0:
+                    v0 = p["a"][:3].astype(np.float64)
+                    e1 = np.array([p["a"][3], p["b"][0], p["b"][1]], dtype=np.float64)
+                    e2 = np.array([p["b"][2], p["b"][3], p["e2z"]], dtype=np.float64)
+                    pv = np.cross(d, e2)
+                    det = e1 @ pv
+                    if det == 0:
+                        continue
+                    tv = org - v0
+                    u = (tv @ pv) / det
+                    qv = np.cross(tv, e1)
+                    v = (d @ qv) / det
+                    t = (e2 @ qv) / det
+                    ok = 0 <= u <= 1 and v >= 0 and u + v <= 1 and t > 0.001
+                else:
+                    c, rad = p["a"][:3].astype(np.float64), float(p["a"][3])
+                    oc = org - c
+                    a_, b_, c_ = d @ d, 2 * (oc @ d), oc @ oc - rad * rad
+                    disc = b_ * b_ - 4 * a_ * c_
+                    ok = disc > 0
+                    if ok:
+                        t = (-b_ - np.sqrt(disc)) / (2 * a_)
+                        ok = t > 0.001
+                if ok and (t < best_t):
+                    best_t, best = t, int(p["orig"])
+            continue
+        nd = wide[cur]
+        for s in range(4):
+            ch = int(nd["child"][s])
+            if ch == 0xFFFFFFFF:
+                continue
+            lo, hi = nd["plane"][:3, s].astype(np.float64), nd["plane"][3:, s].astype(np.float64)
+            t0, t1 = (lo - org) * inv, (hi - org) * inv
+            tn, tf = np.minimum(t0, t1).max(), np.maximum(t0, t1).min()
+            if max(tn, 0.001) <= min(tf, best_t):
+                stack.append(ch)
+    return best, best_t
+
+
+@pytest.mark.parametrize("leaf,box_mode", [(1, 0), (4, 0), (8, 0), (4, 1), (2, 1)])
+def test_wide_layout_covers_and_hits(oracle, leaf, box_mode):
+    for tris, lo, hi in ((scenes.heightfield(14), (-9, 3, -9), (9, 8, 9)), (scenes.spheres_scene(), (-8, 0.5, -8), (8, 6, 8))):
+        nodes = engine.host_build_bvh(tris)
+        wide, prims, depth, stack_entries = engine.host_wide_layout(tris, nodes, leaf, box_mode)
+        n = tris.shape[0]
+        assert prims.shape[0] == n and sorted(prims["orig"].tolist()) == list(range(n))
+        # DFS leaf order of the binary tree
+        rank = oracle.dfs_rank(nodes, n)
+        assert (rank[prims["orig"]] == np.arange(n)).all()
+        # every leaf range is referenced exactly once; every node but the root exactly once
+        seen = np.zeros(n, dtype=np.int32)
+        node_refs = np.zeros(wide.shape[0], dtype=np.int32)
+        for nd in wide:
+            for ch in nd["child"]:
+                ch = int(ch)
+                if ch == 0xFFFFFFFF:
+                    continue
+                if ch & 0x80000000:
+                    s, c = ch & 0x0FFFFFFF, ((ch >> 28) & 7) + 1
+                    assert c <= leaf
+                    seen[s:s + c] += 1
+                else:
+                    node_refs[ch] += 1
+        assert (seen == 1).all() and (node_refs[1:] == 1).all() and node_refs[0] == 0
+        assert stack_entries >= 3 * depth
+        rs = np.random.RandomState(2)
+        hits = 0
+        for _ in range(60):
+            org = rs.uniform(lo, hi).astype(np.float32)
+            d = rs.normal(size=3).astype(np.float32)
+            d[1] = -abs(d[1])
+            h, i, t, _ = oracle.hit(tris, nodes, org, d, "reference")
+            got, gt = _py_closest(wide, prims, org.astype(np.float64), d.astype(np.float64))
+            assert got == (i if h else -1), (org, d, i, got, t, gt)
+            hits += h
+        assert hits > 10
+
+
+def test_wide_layout_rejects_malformed_tree():
+    tris = scenes.heightfield(4)
+    nodes = engine.host_build_bvh(tris)
+    bad = nodes.copy()
+    bad["left"][-1] = bad.shape[0] - 1  # root points at itself
+    with pytest.raises(engine.RtError):
+        engine.host_wide_layout(tris, bad)
+    bad = nodes.copy()
+    leaf = np.nonzero(bad["left"] == bad["right"])[0]
+    bad["left"][leaf[0]] = bad["right"][leaf[0]] = bad["left"][leaf[1]]  # a primitive referenced twice
+    with pytest.raises(engine.RtError):
+        engine.host_wide_layout(tris, bad)
+
+
+def test_scene_generators_are_deterministic():
+    a = scenes.heightfield(10)
+    b = scenes.heightfield(10)
+    assert a.tobytes() == b.tobytes()
+    assert a.shape[0] == 2 * 10 * 10 + 2
+    assert a["shapeType"][0] == 0 and a["matType"][0] == 3  # the light comes first
+    assert (a["texIdx"] == -1).all()
+    assert np.isfinite(a["normal"]).all()
+    assert scenes.heightfield(224).shape[0] == 100352 + 2
