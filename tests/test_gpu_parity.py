@@ -18,9 +18,9 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _engine(tris, nx, ny, ns, depth, cam, **opts):
+def _engine(tris, nx, ny, ns, depth, cam, opts=None):
     eng = rt_amd.PbrtEngine(nx, ny, ns, device=0)
-    for k, v in opts.items():
+    for k, v in (opts or {}).items():
         eng.setOption(k, v)
     eng.setTriangles(tris)
     eng.buildBvh()
@@ -156,7 +156,7 @@ def test_device_layout_options_do_not_change_results(leaf, box_mode):
     want = base.render()
     want_ids, want_t = base.tracePrimary()
     base.close()
-    eng = _engine(tris, 96, 54, 3, 8, scenes.BENCH_CAMERA, **{engine.OPT_LEAF_SIZE: leaf, engine.OPT_BOX_MODE: box_mode})
+    eng = _engine(tris, 96, 54, 3, 8, scenes.BENCH_CAMERA, {engine.OPT_LEAF_SIZE: leaf, engine.OPT_BOX_MODE: box_mode})
     assert eng.render().tobytes() == want.tobytes()
     ids, ts = eng.tracePrimary()
     assert ids.tobytes() == want_ids.tobytes() and ts.tobytes() == want_t.tobytes()
