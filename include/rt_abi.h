@@ -116,12 +116,17 @@ int rt_set_camera(rt_ctx *ctx, const float lookfrom[3], const float lookat[3], f
 enum {
     RT_OPT_MAX_DEPTH = 1,   /* ITER_NUM, pbrt_engine.cu:458 (default 50) */
     RT_OPT_HONOR_VFOV = 2,  /* default 0 */
-    RT_OPT_LEAF_SIZE = 3,   /* primitives per device leaf, 1..8 (default 4); applies at next build */
+    RT_OPT_LEAF_SIZE = 3,   /* primitives per device leaf, 1..8 (default 1); applies at next build */
     RT_OPT_BOX_MODE = 4,    /* 0 = re-fitted boxes + one small pad (default), 1 = the reference's
                                cumulatively padded boxes (triangle.h:28-31,76-85) */
     RT_OPT_SHARD_RANK = 5,  /* multi-GPU tile sharding: this context renders the 8x8 tiles with */
     RT_OPT_SHARD_WORLD = 6, /*   tile_index % world == rank; other pixels are written as 0 */
-    RT_OPT_KERNEL = 7       /* path kernel variant, see DESIGN.md (default 0) */
+    RT_OPT_KERNEL = 7,      /* kernel variant, see DESIGN.md: 0 = one wave per tile, 1 = persistent waves
+                               with per-lane refill (default) */
+    RT_OPT_REFILL_THRESHOLD = 8, /* kernel 1: refill when fewer than this many of 64 lanes still traverse */
+    RT_OPT_WAVES_PER_CU = 9,     /* kernel 1: persistent waves launched per CU */
+    RT_OPT_LDS_STACK = 10,       /* kernel 1: stack entries per lane kept in LDS (the rest spill to HBM) */
+    RT_OPT_NODE_FORMAT = 11      /* kernel 1: 0 = 128-byte float nodes, 1 = 64-byte quantized nodes (default) */
 };
 int rt_set_option(rt_ctx *ctx, int option, int64_t value);
 int rt_get_option(rt_ctx *ctx, int option, int64_t *value);
@@ -151,10 +156,10 @@ int rt_test_introsort(const float *key, int32_t *idx, int n);
 /* The host builder alone (no GPU needed): out must hold 2n-1 nodes. */
 int rt_test_build_bvh(const rt_triangle148 *tris, int n, int64_t rand_calls_before, rt_bvh_node32 *out);
 /* The device layout alone (no GPU needed).  Sizes first (pass NULL buffers), then the copies:
- * wide_nodes: 128 bytes each; prims: 48 bytes each (DFS leaf order); info[4] = {n_wide, n_prims,
+ * wide_nodes: 128 bytes each; quant_nodes: 64 bytes each (same indices); prims: 48 bytes each (DFS leaf order); info[4] = {n_wide, n_prims,
  * depth, stack_entries}. */
 int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size,
-                        int box_mode, void *wide_nodes, void *prims, int32_t info[4]);
+                        int box_mode, void *wide_nodes, void *quant_nodes, void *prims, int32_t info[4]);
 
 #ifdef __cplusplus
 }

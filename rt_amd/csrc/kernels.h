@@ -11,6 +11,7 @@ namespace rtamd {
 
 struct KernelScene {
     const float4 *nodes; // WideNode[], 8 float4 each
+    const uint4 *qnodes; // QuantNode[], 4 uint4 each (same indices)
     const float4 *prims; // DevPrim[], 3 float4 each, DFS leaf order
     const float4 *shade; // DevShade[], 1 float4 each
     const DevMat *mats;  // RT_MAT_NUM entries
@@ -29,6 +30,17 @@ hipError_t launch_trace_primary(const KernelScene &S, const KernelFrame &F, int 
                                 hipStream_t stream);
 hipError_t launch_trace_rays(const KernelScene &S, int stack_entries, const float *org_dir6, int n, int32_t *ids,
                              float *ts, unsigned long long *counter, hipStream_t stream);
+// persistent-wave variant (kernel 1): mode 0 = render, 1 = primary ids
+struct PersistLaunch {
+    unsigned int *band_counters; // 8 counters, zeroed by the caller on the same stream
+    uint32_t *spill;             // (stack_entries - lds_entries) * grid_waves * 64 words
+    int lds_entries;
+    int threshold;
+    int grid_waves;
+    int node_format; // 0 = WideNode (128 B float), 1 = QuantNode (64 B)
+};
+hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &F, const PersistLaunch &L, float *fb,
+                             int32_t *ids, float *ts, hipStream_t stream);
 hipError_t launch_render(const KernelScene &S, const KernelFrame &F, int stack_entries, float *fb, hipStream_t stream);
 
 } // namespace rtamd

@@ -502,6 +502,334 @@ __global__ void __launch_bounds__(64) k_render(KernelScene S, KernelFrame F, flo
     add_rays(F.ray_counter, nr);
 }
 
+// ------------------------------------------------------------------ persistent kernel (variant 1)
+// Persistent waves with per-lane refill (after Aila & Laine's persistent while-while tracer): the
+// traversal state of every lane lives in registers + its LDS stack column ACROSS rays, so a lane whose
+// ray has finished does not wait for the slowest ray of the wave: when fewer than `threshold` lanes
+// are still traversing, the wave leaves the traversal loop, the finished lanes shade / start their
+// next sample / fetch a new pixel, and all lanes re-enter the traversal loop together.  Pixels are
+// handed out from eight band counters (one band of tiles per XCD, so each XCD's L2 sees one region of
+// the image; a wave that finds its band empty steals from the next).  Every pixel carries its own RNG
+// stream (seed 1995 + pixel_index), so which lane renders it does not change the result.
+//
+// Stack: the first `lds_entries` entries of a lane's traversal stack are in LDS ([entry][lane]), the
+// rest spill to a global array ([entry][global lane]); the spill path is only taken by unusually deep
+// pops, which keeps LDS per wave small and occupancy high.
+struct Trav {
+    float idx, idy, idz, nox, noy, noz;
+    int nxi, nyi, nzi;
+    float best_t;
+    int best_rank;
+    uint32_t cur;
+    int sp;
+};
+
+__device__ __forceinline__ void trav_begin(Trav &T, const Ray &r) {
+    T.idx = safe_inv(r.d.x);
+    T.idy = safe_inv(r.d.y);
+    T.idz = safe_inv(r.d.z);
+    T.nox = -r.o.x * T.idx;
+    T.noy = -r.o.y * T.idy;
+    T.noz = -r.o.z * T.idz;
+    T.nxi = r.d.x < 0.0f ? 3 : 0;
+    T.nyi = r.d.y < 0.0f ? 4 : 1;
+    T.nzi = r.d.z < 0.0f ? 5 : 2;
+    T.best_t = FLT_MAX;
+    T.best_rank = RT_NO_HIT;
+    T.cur = 0;
+    T.sp = 0;
+}
+
+struct StackRef {
+    uint32_t *lds;   // this lane's column, stride 64
+    uint32_t *spill; // this lane's column, stride spill_stride
+    int lds_entries;
+    uint32_t spill_stride;
+};
+__device__ __forceinline__ void stk_push(const StackRef &K, int &sp, uint32_t v) {
+    if (sp < K.lds_entries)
+        K.lds[sp * 64] = v;
+    else
+        K.spill[(size_t)(sp - K.lds_entries) * K.spill_stride] = v;
+    sp++;
+}
+__device__ __forceinline__ uint32_t stk_pop(const StackRef &K, int &sp) {
+    sp--;
+    return sp < K.lds_entries ? K.lds[sp * 64] : K.spill[(size_t)(sp - K.lds_entries) * K.spill_stride];
+}
+
+// sort the (up to four) hit children by entry distance, continue with the nearest, push the others far-first
+#define RT_SORT_AND_PUSH()                                                                                             \
+    RT_CSWAP(k0, k1)                                                                                                   \
+    RT_CSWAP(k2, k3)                                                                                                   \
+    RT_CSWAP(k0, k2)                                                                                                   \
+    RT_CSWAP(k1, k3)                                                                                                   \
+    RT_CSWAP(k1, k2)                                                                                                   \
+    if (k0 != 0xFFFFFFFFu) {                                                                                           \
+        T.cur = sel4(ch, k0 & 3u);                                                                                     \
+        if (k1 != 0xFFFFFFFFu) {                                                                                       \
+            if (k2 != 0xFFFFFFFFu) {                                                                                   \
+                if (k3 != 0xFFFFFFFFu) stk_push(K, T.sp, sel4(ch, k3 & 3u));                                           \
+                stk_push(K, T.sp, sel4(ch, k2 & 3u));                                                                  \
+            }                                                                                                          \
+            stk_push(K, T.sp, sel4(ch, k1 & 3u));                                                                      \
+        }                                                                                                              \
+        return true;                                                                                                   \
+    }
+
+// one traversal step: one wide node, or one leaf.  returns false when the ray is finished.
+// FMT 0: 128-byte float nodes (WideNode).  FMT 1: 64-byte quantized nodes (QuantNode).
+template <int FMT>
+__device__ __forceinline__ bool trav_step(Trav &T, const KernelScene &S, const Ray &r, const StackRef &K) {
+    if (!(T.cur & kLeafBit)) {
+        uint32_t k0, k1, k2, k3;
+        if (FMT == 0) {
+            const float4 *n = S.nodes + 8 * (size_t)T.cur;
+            const float4 nx = n[T.nxi], ny = n[T.nyi], nz = n[T.nzi];
+            const float4 fx = n[3 - T.nxi], fy = n[5 - T.nyi], fz = n[7 - T.nzi];
+            const uint4 ch = *reinterpret_cast<const uint4 *>(n + 6);
+#define RT_SLAB(K_, C, I)                                                                                              \
+    {                                                                                                                  \
+        float tn = fmaxf(fmaxf(__builtin_fmaf(nx.C, T.idx, T.nox), __builtin_fmaf(ny.C, T.idy, T.noy)),                \
+                         fmaxf(__builtin_fmaf(nz.C, T.idz, T.noz), 0.001f));                                           \
+        float tf = fminf(fminf(__builtin_fmaf(fx.C, T.idx, T.nox), __builtin_fmaf(fy.C, T.idy, T.noy)),                \
+                         fminf(__builtin_fmaf(fz.C, T.idz, T.noz), T.best_t));                                         \
+        K_ = (tn <= tf) ? ((__float_as_uint(tn) & ~3u) | I) : 0xFFFFFFFFu;                                             \
+    }
+            RT_SLAB(k0, x, 0u)
+            RT_SLAB(k1, y, 1u)
+            RT_SLAB(k2, z, 2u)
+            RT_SLAB(k3, w, 3u)
+#undef RT_SLAB
+            RT_SORT_AND_PUSH()
+        } else {
+            const uint4 *n = S.qnodes + 4 * (size_t)T.cur;
+            const uint4 h = n[0], qa = n[1], qb = n[2], ch = n[3];
+            // grid step per axis (a power of two) folded into the ray's reciprocal direction
+            const float sx = __uint_as_float((h.w & 0xFFu) << 23) * T.idx;
+            const float sy = __uint_as_float(((h.w >> 8) & 0xFFu) << 23) * T.idy;
+            const float sz = __uint_as_float(((h.w >> 16) & 0xFFu) << 23) * T.idz;
+            const float ax = __builtin_fmaf(__uint_as_float(h.x), T.idx, T.nox);
+            const float ay = __builtin_fmaf(__uint_as_float(h.y), T.idy, T.noy);
+            const float az = __builtin_fmaf(__uint_as_float(h.z), T.idz, T.noz);
+            const bool ngx = T.nxi != 0, ngy = T.nyi != 1, ngz = T.nzi != 2;
+            const uint32_t nqx = ngx ? qa.y : qa.x, fqx = ngx ? qa.x : qa.y;
+            const uint32_t nqy = ngy ? qa.w : qa.z, fqy = ngy ? qa.z : qa.w;
+            const uint32_t nqz = ngz ? qb.y : qb.x, fqz = ngz ? qb.x : qb.y;
+#define RT_QB(W, SH) ((float)(((W) >> (SH)) & 0xFFu))
+#define RT_SLABQ(K_, SH, I)                                                                                            \
+    {                                                                                                                  \
+        float tn = fmaxf(fmaxf(__builtin_fmaf(RT_QB(nqx, SH), sx, ax), __builtin_fmaf(RT_QB(nqy, SH), sy, ay)),        \
+                         fmaxf(__builtin_fmaf(RT_QB(nqz, SH), sz, az), 0.001f));                                       \
+        float tf = fminf(fminf(__builtin_fmaf(RT_QB(fqx, SH), sx, ax), __builtin_fmaf(RT_QB(fqy, SH), sy, ay)),        \
+                         fminf(__builtin_fmaf(RT_QB(fqz, SH), sz, az), T.best_t));                                     \
+        K_ = (tn <= tf) ? ((__float_as_uint(tn) & ~3u) | I) : 0xFFFFFFFFu;                                             \
+    }
+            RT_SLABQ(k0, 0, 0u)
+            RT_SLABQ(k1, 8, 1u)
+            RT_SLABQ(k2, 16, 2u)
+            RT_SLABQ(k3, 24, 3u)
+#undef RT_SLABQ
+#undef RT_QB
+            RT_SORT_AND_PUSH()
+        }
+    } else {
+        const uint32_t start = T.cur & kLeafStartMask;
+        const uint32_t cnt = ((T.cur >> 28) & 7u) + 1u;
+        for (uint32_t i = 0; i < cnt; i++) {
+            float t;
+            if (prim_test(S.prims, start + i, r, t)) {
+                int rk = (int)(start + i);
+                if (t < T.best_t || (t == T.best_t && rk < T.best_rank)) {
+                    T.best_t = t;
+                    T.best_rank = rk;
+                }
+            }
+        }
+    }
+    if (T.sp == 0) return false;
+    T.cur = stk_pop(K, T.sp);
+    return true;
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// which XCD this wave runs on (HW_REG_XCC_ID, bits 3:0): used for L2 affinity only, never for correctness
+__device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u; }
+
+__device__ __forceinline__ uint32_t band_begin(uint32_t n_tiles, uint32_t b) { return (uint32_t)(((uint64_t)n_tiles * b) >> 3); }
+
+// Wave-cooperative pixel fetch.  Must be called by all 64 lanes together.  The wave keeps a private run
+// of slots [q.next, q.end) taken from its XCD's band with ONE atomic per CHUNK slots (a returning atomic
+// costs about a microsecond: per-ray fetches would dominate short primary rays); `need` lanes take
+// consecutive slots from it.  When the band is empty the wave steals from the next one; after all eight
+// are empty the remaining `need` lanes get false.  slot = local tile index * 64 + lane-in-tile.
+struct SlotQueue { // wave-uniform
+    uint32_t next, end, bands_tried;
+};
+template <uint32_t CHUNK>
+__device__ __forceinline__ bool fetch_slot(unsigned int *band_counters, uint32_t n_tiles, uint32_t home, SlotQueue &q,
+                                           bool need, uint32_t &slot) {
+    const uint32_t lane = lane_id();
+    for (int guard = 0; guard < 64; guard++) {
+        const unsigned long long mask = __ballot(need);
+        if (mask == 0ull) break;
+        const uint32_t avail = q.end - q.next;
+        if (avail == 0u) {
+            if (q.bands_tried >= 8u) break;
+            const uint32_t b = (home + q.bands_tried) & 7u;
+            const uint32_t begin = band_begin(n_tiles, b), end = band_begin(n_tiles, b + 1u);
+            const uint32_t band_slots = (end - begin) * 64u;
+            uint32_t base = 0;
+            if (lane == 0u) base = atomicAdd(&band_counters[b], CHUNK);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (base >= band_slots) {
+                q.bands_tried++;
+            } else {
+                q.next = begin * 64u + base;
+                q.end = begin * 64u + (base + CHUNK < band_slots ? base + CHUNK : band_slots);
+            }
+            continue;
+        }
+        const uint32_t cnt = (uint32_t)__popcll(mask);
+        const uint32_t before = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (need && before < avail) {
+            slot = q.next + before;
+            need = false;
+        }
+        q.next += cnt < avail ? cnt : avail;
+    }
+    return !need;
+}
+
+struct PersistArgs {
+    unsigned int *band_counters; // 8, zeroed before the launch
+    uint32_t *spill;             // [spill_entries][total lanes]
+    int lds_entries;
+    int threshold;               // leave the traversal loop when fewer lanes than this are traversing
+    uint32_t total_lanes;
+};
+
+// MODE 0: render() (pbrt_engine.cu:569-595).  MODE 1: primary ray of sample 0 per pixel -> hit id, t.
+template <int MODE, int FMT>
+__global__ void __launch_bounds__(64) k_persistent(KernelScene S, KernelFrame F, PersistArgs P, float *fb, int32_t *ids,
+                                                   float *ts) {
+    const uint32_t lane = threadIdx.x;
+    StackRef K;
+    K.lds = s_stack + lane;
+    K.spill = P.spill + (size_t)blockIdx.x * 64u + lane;
+    K.lds_entries = P.lds_entries;
+    K.spill_stride = P.total_lanes;
+    const uint32_t home = xcc_id();
+    const uint32_t n_tiles = (uint32_t)F.n_local_tiles;
+    SlotQueue q;
+    q.next = q.end = q.bands_tried = 0u;
+
+    // per-lane path state
+    bool has_pixel = false, retired = false, tracing = false, result_ready = false, need_primary = false;
+    int pi = 0, pj = 0, pixel_index = 0;
+    Rng g;
+    g.v0 = g.v1 = g.v2 = g.v3 = g.v4 = g.d = 0;
+    V3 col = mk(0, 0, 0), thr = mk(1, 1, 1);
+    int k = 0, bounce = 0;
+    Ray cur;
+    cur.o = mk(0, 0, 0);
+    cur.d = mk(0, 0, 1);
+    Trav T;
+    trav_begin(T, cur);
+    uint32_t nr = 0;
+
+    for (;;) {
+        // ---------------- refill phase: lanes that are not traversing
+        if (has_pixel && result_ready) {
+            result_ready = false;
+            Hit h;
+            h.t = T.best_t;
+            h.rank = T.best_rank;
+            if (MODE == 1) {
+                if (h.rank != RT_NO_HIT) {
+                    ids[pixel_index] = __float_as_int(S.prims[3 * (size_t)h.rank + 2].z);
+                    ts[pixel_index] = h.t;
+                } else {
+                    ids[pixel_index] = -1;
+                    ts[pixel_index] = 0.0f;
+                }
+                has_pixel = false;
+            } else {
+                bool clamp;
+                bool go_on = shade_bounce(S, h, cur, thr, g, clamp);
+                bounce++;
+                if (!go_on || bounce >= F.max_depth) {
+                    if (clamp) clip_color(thr);
+                    col = vadd(col, thr);
+                    k++;
+                    if (k == F.ns) {
+                        float kk = (float)(1.0 / (double)(float)F.ns);
+                        col = mk(col.x * kk, col.y * kk, col.z * kk);
+                        clip_color(col);
+                        fb[3 * (size_t)pixel_index + 0] = col.x;
+                        fb[3 * (size_t)pixel_index + 1] = col.y;
+                        fb[3 * (size_t)pixel_index + 2] = col.z;
+                        has_pixel = false;
+                    } else {
+                        need_primary = true;
+                    }
+                }
+            }
+        }
+        {
+            uint32_t slot = 0;
+            const bool need = !has_pixel && !retired;
+            const bool got = fetch_slot<64u>(P.band_counters, n_tiles, home, q, need, slot);
+            if (need) {
+                if (!got) {
+                    retired = true;
+                } else {
+                    const uint32_t local = slot >> 6, within = slot & 63u;
+                    const uint32_t gt = local * (uint32_t)F.shard_world + (uint32_t)F.shard_rank;
+                    const int tx = (int)(gt % (uint32_t)F.tiles_x), ty = (int)(gt / (uint32_t)F.tiles_x);
+                    pi = tx * 8 + (int)(within & 7u);
+                    pj = ty * 8 + (int)(within >> 3);
+                    if (pi < F.nx && pj < F.ny) { // ragged edge tiles: the slot is simply dropped
+                        pixel_index = pj * F.nx + pi;
+                        rng_init(g, (uint64_t)(1995 + pixel_index));
+                        col = mk(0, 0, 0);
+                        k = 0;
+                        has_pixel = true;
+                        need_primary = true;
+                    }
+                }
+            }
+        }
+        if (has_pixel && !tracing) {
+            if (need_primary) {
+                cur = primary_ray(F.cam, pi, pj, F.nx, F.ny, g);
+                thr = mk(1.0f, 1.0f, 1.0f);
+                bounce = 0;
+                need_primary = false;
+            }
+            trav_begin(T, cur);
+            tracing = true;
+            nr++;
+        }
+        if (__ballot(!retired) == 0ull) break;
+
+        // ---------------- traversal phase
+        for (;;) {
+            const unsigned long long act = __ballot(tracing);
+            if (act == 0ull) break;
+            if ((int)__popcll(act) < P.threshold && __ballot(!tracing && !retired) != 0ull) break;
+            if (tracing) {
+                if (!trav_step<FMT>(T, S, cur, K)) {
+                    tracing = false;
+                    result_ready = true;
+                }
+            }
+        }
+    }
+    add_rays(F.ray_counter, nr);
+}
+
 // ------------------------------------------------------------------ launchers (host)
 static inline hipError_t lds_bytes_ok(int stack_entries, size_t &bytes) {
     bytes = (size_t)stack_entries * 64 * sizeof(uint32_t);
@@ -531,6 +859,30 @@ hipError_t launch_render(const KernelScene &S, const KernelFrame &F, int stack_e
     if (lds_bytes_ok(stack_entries, lds) != hipSuccess) return hipErrorInvalidValue;
     if (F.n_local_tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_render, dim3(F.n_local_tiles), dim3(64), lds, stream, S, F, fb);
+    return hipGetLastError();
+}
+
+hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &F, const PersistLaunch &L, float *fb,
+                             int32_t *ids, float *ts, hipStream_t stream) {
+    if (F.n_local_tiles <= 0) return hipSuccess;
+    if (L.lds_entries < 1 || L.grid_waves < 1) return hipErrorInvalidValue;
+    size_t lds = (size_t)L.lds_entries * 64 * sizeof(uint32_t);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    PersistArgs P;
+    P.band_counters = L.band_counters;
+    P.spill = L.spill;
+    P.lds_entries = L.lds_entries;
+    P.threshold = L.threshold;
+    P.total_lanes = (uint32_t)L.grid_waves * 64u;
+    const dim3 grid(L.grid_waves), block(64);
+    if (mode == 0 && L.node_format == 0)
+        hipLaunchKernelGGL((k_persistent<0, 0>), grid, block, lds, stream, S, F, P, fb, ids, ts);
+    else if (mode == 0)
+        hipLaunchKernelGGL((k_persistent<0, 1>), grid, block, lds, stream, S, F, P, fb, ids, ts);
+    else if (L.node_format == 0)
+        hipLaunchKernelGGL((k_persistent<1, 0>), grid, block, lds, stream, S, F, P, fb, ids, ts);
+    else
+        hipLaunchKernelGGL((k_persistent<1, 1>), grid, block, lds, stream, S, F, P, fb, ids, ts);
     return hipGetLastError();
 }
 

@@ -28,14 +28,19 @@ struct rt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // NX/NY/NS, include/RT/pbrt_engine.h:24-26 ; ITER_NUM, pbrt_engine.cu:458
     int nx = 640, ny = 360, ns = 10, max_depth = 50;
-    int honor_vfov = 0, leaf_size = 4, box_mode = 0, shard_rank = 0, shard_world = 1, kernel_variant = 0;
+    int honor_vfov = 0, leaf_size = 1, box_mode = 0, shard_rank = 0, shard_world = 1, kernel_variant = 1;
+    int refill_threshold = 40, waves_per_cu = 16, lds_stack = 16, node_format = 1;
+    int n_cus = 256;
+    unsigned int *d_bands = nullptr;
+    uint32_t *d_spill = nullptr;
+    size_t spill_words = 0;
 
     std::vector<rt_triangle148> tris;
     std::vector<rt_bvh_node32> bnodes;
     WideBvh wide;
     bool scene_on_device = false;
 
-    void *d_nodes = nullptr, *d_prims = nullptr, *d_shade = nullptr;
+    void *d_nodes = nullptr, *d_qnodes = nullptr, *d_prims = nullptr, *d_shade = nullptr;
     DevMat *d_mats = nullptr;
     float *d_fb = nullptr;
     size_t fb_pixels = 0;
@@ -112,9 +117,10 @@ void camera_basis(DevCamera &c, const float lookfrom[3], const float lookat[3], 
 
 void free_scene(rt_ctx *c) {
     if (c->d_nodes) (void)hipFree(c->d_nodes);
+    if (c->d_qnodes) (void)hipFree(c->d_qnodes);
     if (c->d_prims) (void)hipFree(c->d_prims);
     if (c->d_shade) (void)hipFree(c->d_shade);
-    c->d_nodes = c->d_prims = c->d_shade = nullptr;
+    c->d_nodes = c->d_qnodes = c->d_prims = c->d_shade = nullptr;
     c->scene_on_device = false;
 }
 
@@ -128,6 +134,9 @@ int upload_scene(rt_ctx *c) {
     size_t nb = c->wide.nodes.size() * sizeof(WideNode), pb = c->wide.prims.size() * sizeof(DevPrim),
            sb = c->wide.shade.size() * sizeof(DevShade);
     HIPCHK(c, hipMalloc(&c->d_nodes, nb));
+    size_t qb = c->wide.qnodes.size() * sizeof(QuantNode);
+    HIPCHK(c, hipMalloc(&c->d_qnodes, qb));
+    HIPCHK(c, hipMemcpyAsync(c->d_qnodes, c->wide.qnodes.data(), qb, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMalloc(&c->d_prims, pb));
     HIPCHK(c, hipMalloc(&c->d_shade, sb));
     HIPCHK(c, hipMemcpyAsync(c->d_nodes, c->wide.nodes.data(), nb, hipMemcpyHostToDevice, c->stream));
@@ -192,6 +201,7 @@ void fill_frame(rt_ctx *c, KernelFrame &F) {
 KernelScene scene_of(rt_ctx *c) {
     KernelScene S;
     S.nodes = (const float4 *)c->d_nodes;
+    S.qnodes = (const uint4 *)c->d_qnodes;
     S.prims = (const float4 *)c->d_prims;
     S.shade = (const float4 *)c->d_shade;
     S.mats = c->d_mats;
@@ -207,6 +217,27 @@ void fill_stats(rt_ctx *c, rt_stats *st, uint64_t rays, float ms, double total_m
     st->prims = c->wide.prims.size();
     st->stack_entries = c->wide.stack_entries;
     st->reserved = 0;
+}
+
+// kernel variant 1: zero the band counters, size the spill area, fill the launch record
+int prepare_persistent(rt_ctx *c, PersistLaunch &L) {
+    L.grid_waves = c->n_cus * c->waves_per_cu;
+    L.lds_entries = c->lds_stack < c->wide.stack_entries ? c->lds_stack : c->wide.stack_entries;
+    L.threshold = c->refill_threshold;
+    L.node_format = c->node_format;
+    int spill_entries = c->wide.stack_entries - L.lds_entries;
+    size_t words = (size_t)(spill_entries > 0 ? spill_entries : 1) * (size_t)L.grid_waves * 64;
+    if (words > c->spill_words) {
+        if (c->d_spill) (void)hipFree(c->d_spill);
+        c->d_spill = nullptr;
+        c->spill_words = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_spill, words * sizeof(uint32_t)));
+        c->spill_words = words;
+    }
+    L.spill = c->d_spill;
+    L.band_counters = c->d_bands;
+    HIPCHK(c, hipMemsetAsync(c->d_bands, 0, sizeof(unsigned int) * 8, c->stream));
+    return RT_OK;
 }
 
 double now_ms() {
@@ -275,6 +306,12 @@ int rt_create(rt_ctx **out, int device_id) {
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e);
     if ((e = hipMalloc((void **)&c->d_counter, sizeof(unsigned long long))) != hipSuccess) return bail(e);
     if ((e = hipMalloc((void **)&c->d_mats, sizeof(DevMat) * RT_MAT_NUM)) != hipSuccess) return bail(e);
+    if ((e = hipMalloc((void **)&c->d_bands, sizeof(unsigned int) * 8)) != hipSuccess) return bail(e);
+    {
+        hipDeviceProp_t prop;
+        if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail(e);
+        c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     rt_default_materials(c->mats);
     *out = c;
     return RT_OK;
@@ -287,6 +324,8 @@ int rt_destroy(rt_ctx *c) {
     if (c->d_fb) (void)hipFree(c->d_fb);
     if (c->d_mats) (void)hipFree(c->d_mats);
     if (c->d_counter) (void)hipFree(c->d_counter);
+    if (c->d_bands) (void)hipFree(c->d_bands);
+    if (c->d_spill) (void)hipFree(c->d_spill);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -412,7 +451,24 @@ int rt_set_option(rt_ctx *c, int option, int64_t value) {
         if (c->shard_rank >= c->shard_world) c->shard_rank = 0;
         return RT_OK;
     case RT_OPT_KERNEL:
+        if (value != 0 && value != 1) return fail(c, RT_E_ARG, "kernel variant 0 or 1");
         c->kernel_variant = (int)value;
+        return RT_OK;
+    case RT_OPT_REFILL_THRESHOLD:
+        if (value < 1 || value > 64) return fail(c, RT_E_ARG, "refill threshold 1..64");
+        c->refill_threshold = (int)value;
+        return RT_OK;
+    case RT_OPT_WAVES_PER_CU:
+        if (value < 1 || value > 32) return fail(c, RT_E_ARG, "waves per CU 1..32");
+        c->waves_per_cu = (int)value;
+        return RT_OK;
+    case RT_OPT_LDS_STACK:
+        if (value < 1 || value > 256) return fail(c, RT_E_ARG, "LDS stack entries 1..256");
+        c->lds_stack = (int)value;
+        return RT_OK;
+    case RT_OPT_NODE_FORMAT:
+        if (value != 0 && value != 1) return fail(c, RT_E_ARG, "node format 0 or 1");
+        c->node_format = (int)value;
         return RT_OK;
     default:
         return fail(c, RT_E_ARG, "unknown option");
@@ -429,6 +485,10 @@ int rt_get_option(rt_ctx *c, int option, int64_t *value) {
     case RT_OPT_SHARD_RANK: *value = c->shard_rank; return RT_OK;
     case RT_OPT_SHARD_WORLD: *value = c->shard_world; return RT_OK;
     case RT_OPT_KERNEL: *value = c->kernel_variant; return RT_OK;
+    case RT_OPT_REFILL_THRESHOLD: *value = c->refill_threshold; return RT_OK;
+    case RT_OPT_WAVES_PER_CU: *value = c->waves_per_cu; return RT_OK;
+    case RT_OPT_LDS_STACK: *value = c->lds_stack; return RT_OK;
+    case RT_OPT_NODE_FORMAT: *value = c->node_format; return RT_OK;
     default: return fail(c, RT_E_ARG, "unknown option");
     }
 }
@@ -439,8 +499,16 @@ static int render_into(rt_ctx *c, float *d_fb, rt_stats *st, double t0) {
     HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
     if (c->shard_world > 1) // pixels of other ranks' tiles read as 0, so that a sum over ranks assembles the frame
         HIPCHK(c, hipMemsetAsync(d_fb, 0, (size_t)c->nx * c->ny * 3 * sizeof(float), c->stream));
+    PersistLaunch L;
+    if (c->kernel_variant == 1) {
+        int rc = prepare_persistent(c, L);
+        if (rc) return rc;
+    }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    HIPCHK(c, launch_render(scene_of(c), F, c->wide.stack_entries, d_fb, c->stream));
+    if (c->kernel_variant == 1)
+        HIPCHK(c, launch_persistent(0, scene_of(c), F, L, d_fb, nullptr, nullptr, c->stream));
+    else
+        HIPCHK(c, launch_render(scene_of(c), F, c->wide.stack_entries, d_fb, c->stream));
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float ms = 0.0f;
@@ -498,6 +566,14 @@ int rt_trace_primary(rt_ctx *c, int32_t *tri_id_host, float *t_host, rt_stats *s
     };
     KernelFrame F;
     fill_frame(c, F);
+    PersistLaunch L;
+    if (c->kernel_variant == 1) {
+        int rc2 = prepare_persistent(c, L);
+        if (rc2) {
+            cleanup();
+            return rc2;
+        }
+    }
     hipError_t e = hipSuccess;
     float ms = 0.0f;
     unsigned long long rays = 0;
@@ -506,7 +582,11 @@ int rt_trace_primary(rt_ctx *c, int32_t *tri_id_host, float *t_host, rt_stats *s
         if ((e = hipMemsetAsync(d_ids, 0xFF, px * sizeof(int32_t), c->stream)) != hipSuccess) break;
         if ((e = hipMemsetAsync(d_ts, 0, px * sizeof(float), c->stream)) != hipSuccess) break;
         if ((e = hipEventRecord(c->ev0, c->stream)) != hipSuccess) break;
-        if ((e = launch_trace_primary(scene_of(c), F, c->wide.stack_entries, d_ids, d_ts, c->stream)) != hipSuccess) break;
+        if (c->kernel_variant == 1)
+            e = launch_persistent(1, scene_of(c), F, L, nullptr, d_ids, d_ts, c->stream);
+        else
+            e = launch_trace_primary(scene_of(c), F, c->wide.stack_entries, d_ids, d_ts, c->stream);
+        if (e != hipSuccess) break;
         if ((e = hipEventRecord(c->ev1, c->stream)) != hipSuccess) break;
         if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) break;
         if ((e = hipEventElapsedTime(&ms, c->ev0, c->ev1)) != hipSuccess) break;
@@ -597,7 +677,7 @@ int rt_test_build_bvh(const rt_triangle148 *tris, int n, int64_t rand_calls_befo
 }
 
 int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size,
-                        int box_mode, void *wide_nodes, void *prims, int32_t info[4]) {
+                        int box_mode, void *wide_nodes, void *quant_nodes, void *prims, int32_t info[4]) {
     if (!tris || !nodes || !info) return RT_E_ARG;
     WideBvh w;
     std::string err;
@@ -607,6 +687,7 @@ int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *
     info[2] = w.depth;
     info[3] = w.stack_entries;
     if (wide_nodes) std::memcpy(wide_nodes, w.nodes.data(), w.nodes.size() * sizeof(WideNode));
+    if (quant_nodes) std::memcpy(quant_nodes, w.qnodes.data(), w.qnodes.size() * sizeof(QuantNode));
     if (prims) std::memcpy(prims, w.prims.data(), w.prims.size() * sizeof(DevPrim));
     return RT_OK;
 }

@@ -217,6 +217,65 @@ bool build_wide_bvh(const rt_triangle148 *tris, int n, const rt_bvh_node32 *node
     }
     out.depth = max_level;
     out.stack_entries = 3 * max_level + 2;
+
+    // ---- quantized copy: 8-bit child boxes on a power-of-two grid anchored at the node's min corner ----
+    out.qnodes.resize(out.nodes.size());
+    for (size_t i = 0; i < out.nodes.size(); i++) {
+        const WideNode &w = out.nodes[i];
+        QuantNode q;
+        std::memset(&q, 0, sizeof(q));
+        uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+        for (int a = 0; a < 3; a++) {
+            float org = std::numeric_limits<float>::infinity(), top = -std::numeric_limits<float>::infinity();
+            for (int s = 0; s < 4; s++)
+                if (w.child[s] != kEmptyRef) {
+                    org = std::min(org, w.plane[a][s]);
+                    top = std::max(top, w.plane[3 + a][s]);
+                }
+            double extent = (double)top - (double)org;
+            int e = -100;
+            if (extent > 0.0) {
+                e = (int)std::ceil(std::log2(extent / 255.0));
+                if (e < -100) e = -100;
+            }
+            for (;; e++) { // grow the step until every decoded plane is conservative
+                bool ok = true;
+                double step = std::ldexp(1.0, e);
+                for (int s = 0; s < 4 && ok; s++) {
+                    if (w.child[s] == kEmptyRef) continue;
+                    double lo = std::floor(((double)w.plane[a][s] - (double)org) / step);
+                    double hi = std::ceil(((double)w.plane[3 + a][s] - (double)org) / step);
+                    if (lo < 0.0) lo = 0.0;
+                    if (hi > 255.0 || lo > 255.0) ok = false;
+                    else if ((double)org + lo * step > (double)w.plane[a][s] || (double)org + hi * step < (double)w.plane[3 + a][s])
+                        ok = false;
+                }
+                if (ok) break;
+            }
+            double step = std::ldexp(1.0, e);
+            uint32_t plo = 0, phi = 0;
+            for (int s = 0; s < 4; s++) {
+                uint32_t lo = 255u, hi = 0u; // empty slot: inverted, can never be hit
+                if (w.child[s] != kEmptyRef) {
+                    double l = std::floor(((double)w.plane[a][s] - (double)org) / step);
+                    double h = std::ceil(((double)w.plane[3 + a][s] - (double)org) / step);
+                    lo = (uint32_t)(l < 0.0 ? 0.0 : l);
+                    hi = (uint32_t)h;
+                }
+                plo |= lo << (8 * s);
+                phi |= hi << (8 * s);
+            }
+            qlo[a] = plo;
+            qhi[a] = phi;
+            q.origin[a] = org;
+            q.exps |= (uint32_t)(e + 127) << (8 * a);
+        }
+        q.qx_lo = qlo[0]; q.qx_hi = qhi[0];
+        q.qy_lo = qlo[1]; q.qy_hi = qhi[1];
+        q.qz_lo = qlo[2]; q.qz_hi = qhi[2];
+        for (int s = 0; s < 4; s++) q.child[s] = w.child[s];
+        out.qnodes[i] = q;
+    }
     return true;
 }
 

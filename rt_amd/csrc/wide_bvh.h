@@ -13,6 +13,7 @@ namespace rtamd {
 
 struct WideBvh {
     std::vector<WideNode> nodes; // nodes[0] is the root
+    std::vector<QuantNode> qnodes; // the same nodes, quantized (rt_types.h); same indices
     std::vector<DevPrim> prims;  // DFS leaf order of the binary tree
     std::vector<DevShade> shade; // same order
     int depth = 0;               // wide levels below the root node (root = 1)

@@ -191,6 +191,27 @@ def test_wide_layout_covers_and_hits(oracle, leaf, box_mode):
         assert hits > 10
 
 
+def test_quantized_nodes_are_conservative():
+    """64-byte quantized nodes: every decoded child box contains the float child box it came from, and is at
+    most one grid step larger per side; child references are unchanged."""
+    for tris in (scenes.heightfield(30), scenes.spheres_scene()):
+        nodes = engine.host_build_bvh(tris)
+        wide, qn, prims, _, _ = engine.host_wide_layout(tris, nodes, 1, 0, quant=True)
+        assert engine.QUANT_DTYPE.itemsize == 64 and qn.shape[0] == wide.shape[0]
+        assert (qn["child"] == wide["child"]).all()
+        valid = wide["child"] != 0xFFFFFFFF
+        for a in range(3):
+            step = np.ldexp(1.0, ((qn["exps"] >> (8 * a)) & 0xFF).astype(np.int64) - 127)
+            for s in range(4):
+                lo = qn["origin"][:, a].astype(np.float64) + ((qn["q"][:, 2 * a] >> (8 * s)) & 0xFF) * step
+                hi = qn["origin"][:, a].astype(np.float64) + ((qn["q"][:, 2 * a + 1] >> (8 * s)) & 0xFF) * step
+                v = valid[:, s]
+                flo, fhi = wide["plane"][:, a, s].astype(np.float64), wide["plane"][:, 3 + a, s].astype(np.float64)
+                assert (lo[v] <= flo[v]).all() and (hi[v] >= fhi[v]).all()
+                assert (flo[v] - lo[v] <= step[v]).all() and (hi[v] - fhi[v] <= step[v]).all()
+                assert (lo[~v] > hi[~v]).all()  # empty slots are inverted
+
+
 def test_wide_layout_rejects_malformed_tree():
     tris = scenes.heightfield(4)
     nodes = engine.host_build_bvh(tris)

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 --pmc CSVs (one directory per pass) per kernel: tools/pmc_summary.py DIR > summary.json"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+d = sys.argv[1]
+acc = defaultdict(lambda: defaultdict(float))
+calls = defaultdict(lambda: defaultdict(int))
+for f in glob.glob(os.path.join(d, "pass*", "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"].split("(")[0]
+        acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        calls[k][row["Counter_Name"]] += 1
+out = {}
+for k in acc:
+    out[k] = {c: {"sum": v, "dispatches": calls[k][c], "per_dispatch": v / calls[k][c]} for c, v in sorted(acc[k].items())}
+json.dump(out, sys.stdout, indent=1)
