@@ -122,11 +122,13 @@ enum {
     RT_OPT_SHARD_RANK = 5,  /* multi-GPU tile sharding: this context renders the 8x8 tiles with */
     RT_OPT_SHARD_WORLD = 6, /*   tile_index % world == rank; other pixels are written as 0 */
     RT_OPT_KERNEL = 7,      /* kernel variant, see DESIGN.md: 0 = one wave per tile, 1 = persistent waves
-                               with per-lane refill (default) */
+                               with per-lane refill, 2 = 1 + speculative traversal (postponed leaves) */
     RT_OPT_REFILL_THRESHOLD = 8, /* kernel 1: refill when fewer than this many of 64 lanes still traverse */
     RT_OPT_WAVES_PER_CU = 9,     /* kernel 1: persistent waves launched per CU */
     RT_OPT_LDS_STACK = 10,       /* kernel 1: stack entries per lane kept in LDS (the rest spill to HBM) */
-    RT_OPT_NODE_FORMAT = 11      /* kernel 1: 0 = 128-byte float nodes, 1 = 64-byte quantized nodes (default) */
+    RT_OPT_NODE_FORMAT = 11,     /* kernel 1/2: 0 = 128-byte float nodes, 1 = 64-byte quantized nodes (default) */
+    RT_OPT_LEAF_BATCH = 12,      /* kernel 2: primitive tests run when this many lanes have a leaf pending */
+    RT_OPT_OCCUPANCY = 13        /* kernel 1/2, quantized nodes: waves per SIMD the registers are held to: 4, 6, 8 */
 };
 int rt_set_option(rt_ctx *ctx, int option, int64_t value);
 int rt_get_option(rt_ctx *ctx, int option, int64_t *value);

@@ -38,6 +38,9 @@ struct PersistLaunch {
     int threshold;
     int grid_waves;
     int node_format; // 0 = WideNode (128 B float), 1 = QuantNode (64 B)
+    int speculative; // 1 = postpone leaves (speculative traversal)
+    int leaf_batch;
+    int occupancy; // 4, 6 or 8 waves per SIMD the kernel's registers are held to (quantized nodes only)
 };
 hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &F, const PersistLaunch &L, float *fb,
                              int32_t *ids, float *ts, hipStream_t stream);

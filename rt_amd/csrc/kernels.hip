@@ -515,12 +515,19 @@ __global__ void __launch_bounds__(64) k_render(KernelScene S, KernelFrame F, flo
 // Stack: the first `lds_entries` entries of a lane's traversal stack are in LDS ([entry][lane]), the
 // rest spill to a global array ([entry][global lane]); the spill path is only taken by unusually deep
 // pops, which keeps LDS per wave small and occupancy high.
+// hipcc sinks a load into the branch that first uses it; for a node that turns one memory round trip per
+// traversal step into two (boxes, then child references).  Naming the values in an empty asm statement pins
+// every load of the node before the first use of any of them.
+#define RT_PIN4(V) asm volatile("" : "+v"((V).x), "+v"((V).y), "+v"((V).z), "+v"((V).w))
+
+#define RT_REF_NONE 0xFFFFFFFFu /* "no node": has the leaf bit set but is never a real leaf reference */
 struct Trav {
     float idx, idy, idz, nox, noy, noz;
     int nxi, nyi, nzi;
     float best_t;
     int best_rank;
     uint32_t cur;
+    uint32_t pend; // speculative traversal: one postponed leaf
     int sp;
 };
 
@@ -537,6 +544,7 @@ __device__ __forceinline__ void trav_begin(Trav &T, const Ray &r) {
     T.best_t = FLT_MAX;
     T.best_rank = RT_NO_HIT;
     T.cur = 0;
+    T.pend = RT_REF_NONE;
     T.sp = 0;
 }
 
@@ -546,16 +554,23 @@ struct StackRef {
     int lds_entries;
     uint32_t spill_stride;
 };
+// The spill accesses are volatile so that hipcc cannot fold "LDS or global" into one flat_load / flat_store
+// (a flat access waits on both counters and is slower than ds_read even when it lands in LDS).
 __device__ __forceinline__ void stk_push(const StackRef &K, int &sp, uint32_t v) {
-    if (sp < K.lds_entries)
+    if (__builtin_expect(sp < K.lds_entries, 1))
         K.lds[sp * 64] = v;
     else
-        K.spill[(size_t)(sp - K.lds_entries) * K.spill_stride] = v;
+        *(volatile uint32_t *)(K.spill + (size_t)(sp - K.lds_entries) * K.spill_stride) = v;
     sp++;
 }
 __device__ __forceinline__ uint32_t stk_pop(const StackRef &K, int &sp) {
     sp--;
-    return sp < K.lds_entries ? K.lds[sp * 64] : K.spill[(size_t)(sp - K.lds_entries) * K.spill_stride];
+    uint32_t v;
+    if (__builtin_expect(sp < K.lds_entries, 1))
+        v = K.lds[sp * 64];
+    else
+        v = *(volatile uint32_t *)(K.spill + (size_t)(sp - K.lds_entries) * K.spill_stride);
+    return v;
 }
 
 // sort the (up to four) hit children by entry distance, continue with the nearest, push the others far-first
@@ -574,20 +589,24 @@ __device__ __forceinline__ uint32_t stk_pop(const StackRef &K, int &sp) {
             }                                                                                                          \
             stk_push(K, T.sp, sel4(ch, k1 & 3u));                                                                      \
         }                                                                                                              \
-        return true;                                                                                                   \
+        return;                                                                                                        \
     }
 
-// one traversal step: one wide node, or one leaf.  returns false when the ray is finished.
+__device__ __forceinline__ uint32_t pop_or_none(const StackRef &K, int &sp) { return sp == 0 ? RT_REF_NONE : stk_pop(K, sp); }
+
+// one wide node: tests its four child boxes, sets T.cur to the nearest hit child (pushing the others) or to the
+// next stack entry (RT_REF_NONE when the stack is empty).
 // FMT 0: 128-byte float nodes (WideNode).  FMT 1: 64-byte quantized nodes (QuantNode).
 template <int FMT>
-__device__ __forceinline__ bool trav_step(Trav &T, const KernelScene &S, const Ray &r, const StackRef &K) {
-    if (!(T.cur & kLeafBit)) {
+__device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const StackRef &K) {
+    {
         uint32_t k0, k1, k2, k3;
         if (FMT == 0) {
             const float4 *n = S.nodes + 8 * (size_t)T.cur;
             const float4 nx = n[T.nxi], ny = n[T.nyi], nz = n[T.nzi];
             const float4 fx = n[3 - T.nxi], fy = n[5 - T.nyi], fz = n[7 - T.nzi];
-            const uint4 ch = *reinterpret_cast<const uint4 *>(n + 6);
+            uint4 ch = *reinterpret_cast<const uint4 *>(n + 6);
+            RT_PIN4(ch);
 #define RT_SLAB(K_, C, I)                                                                                              \
     {                                                                                                                  \
         float tn = fmaxf(fmaxf(__builtin_fmaf(nx.C, T.idx, T.nox), __builtin_fmaf(ny.C, T.idy, T.noy)),                \
@@ -604,7 +623,11 @@ __device__ __forceinline__ bool trav_step(Trav &T, const KernelScene &S, const R
             RT_SORT_AND_PUSH()
         } else {
             const uint4 *n = S.qnodes + 4 * (size_t)T.cur;
-            const uint4 h = n[0], qa = n[1], qb = n[2], ch = n[3];
+            uint4 h = n[0], qa = n[1], qb = n[2], ch = n[3];
+            RT_PIN4(h);
+            RT_PIN4(qa);
+            RT_PIN4(qb);
+            RT_PIN4(ch);
             // grid step per axis (a power of two) folded into the ray's reciprocal direction
             const float sx = __uint_as_float((h.w & 0xFFu) << 23) * T.idx;
             const float sy = __uint_as_float(((h.w >> 8) & 0xFFu) << 23) * T.idy;
@@ -633,23 +656,36 @@ __device__ __forceinline__ bool trav_step(Trav &T, const KernelScene &S, const R
 #undef RT_QB
             RT_SORT_AND_PUSH()
         }
-    } else {
-        const uint32_t start = T.cur & kLeafStartMask;
-        const uint32_t cnt = ((T.cur >> 28) & 7u) + 1u;
-        for (uint32_t i = 0; i < cnt; i++) {
-            float t;
-            if (prim_test(S.prims, start + i, r, t)) {
-                int rk = (int)(start + i);
-                if (t < T.best_t || (t == T.best_t && rk < T.best_rank)) {
-                    T.best_t = t;
-                    T.best_rank = rk;
-                }
+    }
+    T.cur = pop_or_none(K, T.sp);
+}
+
+// one leaf: tests its primitives; min t, ties to the earlier DFS leaf (pbrt_engine.cu:421-438)
+__device__ __forceinline__ void leaf_test(Trav &T, const KernelScene &S, const Ray &r, uint32_t ref) {
+    const uint32_t start = ref & kLeafStartMask;
+    const uint32_t cnt = ((ref >> 28) & 7u) + 1u;
+    for (uint32_t i = 0; i < cnt; i++) {
+        float t;
+        if (prim_test(S.prims, start + i, r, t)) {
+            int rk = (int)(start + i);
+            if (t < T.best_t || (t == T.best_t && rk < T.best_rank)) {
+                T.best_t = t;
+                T.best_rank = rk;
             }
         }
     }
-    if (T.sp == 0) return false;
-    T.cur = stk_pop(K, T.sp);
-    return true;
+}
+
+// one traversal step: one wide node, or one leaf.  returns false when the ray is finished.
+template <int FMT>
+__device__ __forceinline__ bool trav_step(Trav &T, const KernelScene &S, const Ray &r, const StackRef &K) {
+    if (!(T.cur & kLeafBit)) {
+        node_step<FMT>(T, S, K);
+    } else {
+        leaf_test(T, S, r, T.cur);
+        T.cur = pop_or_none(K, T.sp);
+    }
+    return T.cur != RT_REF_NONE;
 }
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -707,12 +743,17 @@ struct PersistArgs {
     uint32_t *spill;             // [spill_entries][total lanes]
     int lds_entries;
     int threshold;               // leave the traversal loop when fewer lanes than this are traversing
+    int leaf_batch;              // SPEC: run the primitive tests when this many lanes have a leaf pending
     uint32_t total_lanes;
 };
 
 // MODE 0: render() (pbrt_engine.cu:569-595).  MODE 1: primary ray of sample 0 per pixel -> hit id, t.
-template <int MODE, int FMT>
-__global__ void __launch_bounds__(64) k_persistent(KernelScene S, KernelFrame F, PersistArgs P, float *fb, int32_t *ids,
+// SPEC 1: speculative traversal (Aila & Laine): a lane that reaches a leaf postpones it and keeps
+// traversing nodes; the expensive primitive test runs only when `leaf_batch` lanes have one pending (or no
+// lane has node work), so it executes with many lanes instead of the one or two that happen to sit on a leaf.
+// OCC: waves per SIMD the register allocation is held to (__launch_bounds__' second argument).
+template <int MODE, int FMT, int SPEC, int OCC>
+__global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFrame F, PersistArgs P, float *fb, int32_t *ids,
                                                    float *ts) {
     const uint32_t lane = threadIdx.x;
     StackRef K;
@@ -819,8 +860,32 @@ __global__ void __launch_bounds__(64) k_persistent(KernelScene S, KernelFrame F,
             const unsigned long long act = __ballot(tracing);
             if (act == 0ull) break;
             if ((int)__popcll(act) < P.threshold && __ballot(!tracing && !retired) != 0ull) break;
-            if (tracing) {
-                if (!trav_step<FMT>(T, S, cur, K)) {
+            if (SPEC == 0) {
+                if (tracing) {
+                    if (!trav_step<FMT>(T, S, cur, K)) {
+                        tracing = false;
+                        result_ready = true;
+                    }
+                }
+            } else {
+                if (tracing && !(T.cur & kLeafBit)) node_step<FMT>(T, S, K);
+                // park a reached leaf in the pending slot and go on with the next stack entry
+                if (tracing && T.pend == RT_REF_NONE && T.cur != RT_REF_NONE && (T.cur & kLeafBit)) {
+                    T.pend = T.cur;
+                    T.cur = pop_or_none(K, T.sp);
+                }
+                const bool want_leaf = tracing && T.pend != RT_REF_NONE;
+                const unsigned long long leaf_mask = __ballot(want_leaf);
+                if (leaf_mask != 0ull) {
+                    const unsigned long long node_mask = __ballot(tracing && !(T.cur & kLeafBit));
+                    if (node_mask == 0ull || (int)__popcll(leaf_mask) >= P.leaf_batch) {
+                        if (want_leaf) {
+                            leaf_test(T, S, cur, T.pend);
+                            T.pend = RT_REF_NONE;
+                        }
+                    }
+                }
+                if (tracing && T.cur == RT_REF_NONE && T.pend == RT_REF_NONE) {
                     tracing = false;
                     result_ready = true;
                 }
@@ -873,16 +938,31 @@ hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &
     P.spill = L.spill;
     P.lds_entries = L.lds_entries;
     P.threshold = L.threshold;
+    P.leaf_batch = L.leaf_batch;
     P.total_lanes = (uint32_t)L.grid_waves * 64u;
     const dim3 grid(L.grid_waves), block(64);
-    if (mode == 0 && L.node_format == 0)
-        hipLaunchKernelGGL((k_persistent<0, 0>), grid, block, lds, stream, S, F, P, fb, ids, ts);
-    else if (mode == 0)
-        hipLaunchKernelGGL((k_persistent<0, 1>), grid, block, lds, stream, S, F, P, fb, ids, ts);
-    else if (L.node_format == 0)
-        hipLaunchKernelGGL((k_persistent<1, 0>), grid, block, lds, stream, S, F, P, fb, ids, ts);
-    else
-        hipLaunchKernelGGL((k_persistent<1, 1>), grid, block, lds, stream, S, F, P, fb, ids, ts);
+#define RT_LAUNCH(M, Fm, Sp, Oc)                                                                                       \
+    hipLaunchKernelGGL((k_persistent<M, Fm, Sp, Oc>), grid, block, lds, stream, S, F, P, fb, ids, ts)
+#define RT_LAUNCH_OCC(M, Sp)                                                                                           \
+    if (L.occupancy >= 8)                                                                                              \
+        RT_LAUNCH(M, 1, Sp, 8);                                                                                        \
+    else if (L.occupancy >= 6)                                                                                         \
+        RT_LAUNCH(M, 1, Sp, 6);                                                                                        \
+    else                                                                                                               \
+        RT_LAUNCH(M, 1, Sp, 4);
+    const int sel = (mode ? 4 : 0) | (L.node_format ? 2 : 0) | (L.speculative ? 1 : 0);
+    switch (sel) {
+    case 0: RT_LAUNCH(0, 0, 0, 4); break;
+    case 1: RT_LAUNCH(0, 0, 1, 4); break;
+    case 2: RT_LAUNCH_OCC(0, 0) break;
+    case 3: RT_LAUNCH_OCC(0, 1) break;
+    case 4: RT_LAUNCH(1, 0, 0, 4); break;
+    case 5: RT_LAUNCH(1, 0, 1, 4); break;
+    case 6: RT_LAUNCH_OCC(1, 0) break;
+    default: RT_LAUNCH_OCC(1, 1) break;
+    }
+#undef RT_LAUNCH_OCC
+#undef RT_LAUNCH
     return hipGetLastError();
 }
 

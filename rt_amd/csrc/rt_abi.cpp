@@ -29,7 +29,7 @@ struct rt_ctx {
     // NX/NY/NS, include/RT/pbrt_engine.h:24-26 ; ITER_NUM, pbrt_engine.cu:458
     int nx = 640, ny = 360, ns = 10, max_depth = 50;
     int honor_vfov = 0, leaf_size = 1, box_mode = 0, shard_rank = 0, shard_world = 1, kernel_variant = 1;
-    int refill_threshold = 40, waves_per_cu = 16, lds_stack = 16, node_format = 1;
+    int refill_threshold = 48, waves_per_cu = 24, lds_stack = 16, node_format = 1, leaf_batch = 8, occupancy = 6;
     int n_cus = 256;
     unsigned int *d_bands = nullptr;
     uint32_t *d_spill = nullptr;
@@ -225,6 +225,9 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L) {
     L.lds_entries = c->lds_stack < c->wide.stack_entries ? c->lds_stack : c->wide.stack_entries;
     L.threshold = c->refill_threshold;
     L.node_format = c->node_format;
+    L.speculative = c->kernel_variant == 2 ? 1 : 0;
+    L.leaf_batch = c->leaf_batch;
+    L.occupancy = c->occupancy;
     int spill_entries = c->wide.stack_entries - L.lds_entries;
     size_t words = (size_t)(spill_entries > 0 ? spill_entries : 1) * (size_t)L.grid_waves * 64;
     if (words > c->spill_words) {
@@ -451,7 +454,7 @@ int rt_set_option(rt_ctx *c, int option, int64_t value) {
         if (c->shard_rank >= c->shard_world) c->shard_rank = 0;
         return RT_OK;
     case RT_OPT_KERNEL:
-        if (value != 0 && value != 1) return fail(c, RT_E_ARG, "kernel variant 0 or 1");
+        if (value < 0 || value > 2) return fail(c, RT_E_ARG, "kernel variant 0, 1 or 2");
         c->kernel_variant = (int)value;
         return RT_OK;
     case RT_OPT_REFILL_THRESHOLD:
@@ -469,6 +472,14 @@ int rt_set_option(rt_ctx *c, int option, int64_t value) {
     case RT_OPT_NODE_FORMAT:
         if (value != 0 && value != 1) return fail(c, RT_E_ARG, "node format 0 or 1");
         c->node_format = (int)value;
+        return RT_OK;
+    case RT_OPT_LEAF_BATCH:
+        if (value < 1 || value > 64) return fail(c, RT_E_ARG, "leaf batch 1..64");
+        c->leaf_batch = (int)value;
+        return RT_OK;
+    case RT_OPT_OCCUPANCY:
+        if (value != 4 && value != 6 && value != 8) return fail(c, RT_E_ARG, "occupancy 4, 6 or 8");
+        c->occupancy = (int)value;
         return RT_OK;
     default:
         return fail(c, RT_E_ARG, "unknown option");
@@ -489,6 +500,8 @@ int rt_get_option(rt_ctx *c, int option, int64_t *value) {
     case RT_OPT_WAVES_PER_CU: *value = c->waves_per_cu; return RT_OK;
     case RT_OPT_LDS_STACK: *value = c->lds_stack; return RT_OK;
     case RT_OPT_NODE_FORMAT: *value = c->node_format; return RT_OK;
+    case RT_OPT_LEAF_BATCH: *value = c->leaf_batch; return RT_OK;
+    case RT_OPT_OCCUPANCY: *value = c->occupancy; return RT_OK;
     default: return fail(c, RT_E_ARG, "unknown option");
     }
 }
@@ -500,12 +513,12 @@ static int render_into(rt_ctx *c, float *d_fb, rt_stats *st, double t0) {
     if (c->shard_world > 1) // pixels of other ranks' tiles read as 0, so that a sum over ranks assembles the frame
         HIPCHK(c, hipMemsetAsync(d_fb, 0, (size_t)c->nx * c->ny * 3 * sizeof(float), c->stream));
     PersistLaunch L;
-    if (c->kernel_variant == 1) {
+    if (c->kernel_variant >= 1) {
         int rc = prepare_persistent(c, L);
         if (rc) return rc;
     }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    if (c->kernel_variant == 1)
+    if (c->kernel_variant >= 1)
         HIPCHK(c, launch_persistent(0, scene_of(c), F, L, d_fb, nullptr, nullptr, c->stream));
     else
         HIPCHK(c, launch_render(scene_of(c), F, c->wide.stack_entries, d_fb, c->stream));
@@ -567,7 +580,7 @@ int rt_trace_primary(rt_ctx *c, int32_t *tri_id_host, float *t_host, rt_stats *s
     KernelFrame F;
     fill_frame(c, F);
     PersistLaunch L;
-    if (c->kernel_variant == 1) {
+    if (c->kernel_variant >= 1) {
         int rc2 = prepare_persistent(c, L);
         if (rc2) {
             cleanup();
@@ -582,7 +595,7 @@ int rt_trace_primary(rt_ctx *c, int32_t *tri_id_host, float *t_host, rt_stats *s
         if ((e = hipMemsetAsync(d_ids, 0xFF, px * sizeof(int32_t), c->stream)) != hipSuccess) break;
         if ((e = hipMemsetAsync(d_ts, 0, px * sizeof(float), c->stream)) != hipSuccess) break;
         if ((e = hipEventRecord(c->ev0, c->stream)) != hipSuccess) break;
-        if (c->kernel_variant == 1)
+        if (c->kernel_variant >= 1)
             e = launch_persistent(1, scene_of(c), F, L, nullptr, d_ids, d_ts, c->stream);
         else
             e = launch_trace_primary(scene_of(c), F, c->wide.stack_entries, d_ids, d_ts, c->stream);

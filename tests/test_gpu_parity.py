@@ -163,6 +163,30 @@ def test_device_layout_options_do_not_change_results(leaf, box_mode):
     eng.close()
 
 
+@pytest.mark.parametrize("kernel,fmt,thr,batch,lds", [(0, 0, 40, 24, 16), (1, 0, 40, 24, 16), (1, 1, 64, 24, 2), (2, 0, 16, 1, 16),
+                                                     (2, 1, 48, 64, 4), (2, 1, 1, 8, 64)])
+def test_kernel_variants_bit_exact(oracle, kernel, fmt, thr, batch, lds):
+    """Every kernel variant (one wave per tile / persistent refill / speculative), node format (float /
+    quantized), refill threshold, leaf batch and LDS-stack size (small ones force the HBM spill path) returns the
+    oracle's image and hit ids, bit for bit."""
+    opts = {engine.OPT_KERNEL: kernel, engine.OPT_NODE_FORMAT: fmt, engine.OPT_REFILL_THRESHOLD: thr,
+            engine.OPT_LEAF_BATCH: batch, engine.OPT_LDS_STACK: lds, engine.OPT_WAVES_PER_CU: 3}
+    for tris, cam, nx, ny, ns, depth in ((scenes.heightfield(50), scenes.BENCH_CAMERA, 150, 85, 4, 8),
+                                         (scenes.spheres_scene(), scenes.DEFAULT_CAMERA, 90, 50, 3, 30)):
+        eng = _engine(tris, nx, ny, ns, depth, cam, opts)
+        fb = eng.render()
+        rays = eng.last_stats.rays
+        ids, ts = eng.tracePrimary()
+        nodes = eng.getBvhNodes()
+        ocam = oracle.camera(cam["lookfrom"], cam["lookat"], 40.0, nx / ny, cam["aperture"], cam["dist_to_focus"])
+        fb_o, cnt = oracle.render(tris, nodes, oracle.material_table(), ocam, nx, ny, ns, depth, mode=1)
+        ids_o, ts_o, _ = oracle.trace_primary(tris, nodes, ocam, nx, ny, mode=1)
+        assert rays == cnt.rays
+        assert fb.tobytes() == fb_o.tobytes()
+        assert ids.tobytes() == ids_o.tobytes() and ts.tobytes() == ts_o.tobytes()
+        eng.close()
+
+
 def test_injected_nodes_and_cached_render(oracle):
     """rt_set_bvh_nodes with the oracle's node array ("render -cache" reuses the built scene)."""
     tris = scenes.heightfield(20)

@@ -26,13 +26,15 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--frames", type=int, default=1)
     ap.add_argument("--primary", type=int, default=1)
-    ap.add_argument("--leaf", type=ints, default=[4])
+    ap.add_argument("--leaf", type=ints, default=[1])
     ap.add_argument("--box-mode", type=ints, default=[0])
     ap.add_argument("--kernel", type=ints, default=[1])
-    ap.add_argument("--threshold", type=ints, default=[40])
-    ap.add_argument("--waves", type=ints, default=[16])
+    ap.add_argument("--threshold", type=ints, default=[48])
+    ap.add_argument("--waves", type=ints, default=[24])
     ap.add_argument("--lds", type=ints, default=[16])
     ap.add_argument("--fmt", type=ints, default=[1])
+    ap.add_argument("--batch", type=ints, default=[8])
+    ap.add_argument("--occ", type=ints, default=[6])
     args = ap.parse_args()
     tris = scenes.heightfield(args.grid)
     eng = rt_amd.PbrtEngine(args.nx, args.ny, args.spp, device=0)
@@ -40,7 +42,7 @@ def main():
     eng.setMaxDepth(args.depth)
     eng.setCamera(**scenes.BENCH_CAMERA)
     nodes = None
-    for leaf, bm, kv, th, wv, ld, fm in itertools.product(args.leaf, args.box_mode, args.kernel, args.threshold, args.waves, args.lds, args.fmt):
+    for leaf, bm, kv, th, wv, ld, fm, lb, oc in itertools.product(args.leaf, args.box_mode, args.kernel, args.threshold, args.waves, args.lds, args.fmt, args.batch, args.occ):
         eng.setOption(E.OPT_LEAF_SIZE, leaf)
         eng.setOption(E.OPT_BOX_MODE, bm)
         eng.setOption(E.OPT_KERNEL, kv)
@@ -48,12 +50,14 @@ def main():
         eng.setOption(E.OPT_WAVES_PER_CU, wv)
         eng.setOption(E.OPT_LDS_STACK, ld)
         eng.setOption(E.OPT_NODE_FORMAT, fm)
+        eng.setOption(E.OPT_LEAF_BATCH, lb)
+        eng.setOption(E.OPT_OCCUPANCY, oc)
         if nodes is None:
             eng.buildBvh()
             nodes = eng.getBvhNodes()
         else:
             eng.setBvhNodes(nodes)
-        out = {"leaf": leaf, "box_mode": bm, "kernel": kv, "thr": th, "waves": wv, "lds": ld, "fmt": fm}
+        out = {"leaf": leaf, "box_mode": bm, "kernel": kv, "thr": th, "waves": wv, "lds": ld, "fmt": fm, "batch": lb, "occ": oc}
         best = None
         for _ in range(args.frames):
             eng.render()
