@@ -163,6 +163,10 @@ int rt_test_build_bvh(const rt_triangle148 *tris, int n, int64_t rand_calls_befo
 int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size,
                         int box_mode, void *wide_nodes, void *quant_nodes, void *prims, int32_t info[4]);
 
+/* The tile-sharding rule alone (no GPU needed): owner[j*nx+i] = rank that renders pixel (i, j) when the frame
+ * is split over `world` contexts (RT_OPT_SHARD_RANK / RT_OPT_SHARD_WORLD). */
+int rt_test_tile_owner(int nx, int ny, int world, int32_t *owner);
+
 #ifdef __cplusplus
 }
 #endif

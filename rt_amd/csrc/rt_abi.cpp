@@ -705,4 +705,13 @@ int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *
     return RT_OK;
 }
 
+int rt_test_tile_owner(int nx, int ny, int world, int32_t *owner) {
+    if (nx <= 0 || ny <= 0 || world <= 0 || !owner) return RT_E_ARG;
+    // the rule of tile_pixel() / k_persistent in kernels.hip: 8x8 tiles, row-major tile index g, owner = g % world
+    const int tiles_x = (nx + 7) / 8;
+    for (int j = 0; j < ny; j++)
+        for (int i = 0; i < nx; i++) owner[(size_t)j * nx + i] = (int32_t)((((long)(j / 8)) * tiles_x + i / 8) % world);
+    return RT_OK;
+}
+
 } // extern "C"

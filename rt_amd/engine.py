@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_resize", "rt_set_scene", "rt_build_bvh",
     "rt_set_bvh_nodes", "rt_get_bvh_nodes", "rt_default_materials", "rt_set_materials", "rt_set_camera",
     "rt_set_option", "rt_get_option", "rt_render", "rt_render_device", "rt_trace_primary", "rt_trace_rays",
-    "rt_write_ppm", "rt_test_glibc_rand", "rt_test_introsort", "rt_test_build_bvh", "rt_test_wide_layout",
+    "rt_write_ppm", "rt_test_glibc_rand", "rt_test_introsort", "rt_test_build_bvh", "rt_test_wide_layout", "rt_test_tile_owner",
 ]
 
 
@@ -98,6 +98,7 @@ def load_library(path: str = LIB_PATH):
     lib.rt_test_glibc_rand.argtypes = [C.c_uint32, C.c_int, vp]
     lib.rt_test_introsort.argtypes = [vp, vp, C.c_int]
     lib.rt_test_build_bvh.argtypes = [vp, C.c_int, C.c_int64, vp]
+    lib.rt_test_tile_owner.argtypes = [C.c_int, C.c_int, C.c_int, vp]
     lib.rt_test_wide_layout.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     for name in ABI_SYMBOLS:
         if name != "rt_last_error":
@@ -128,6 +129,16 @@ def host_build_bvh(tris: np.ndarray, rand_calls_before: int = 0) -> np.ndarray:
     rc = lib.rt_test_build_bvh(_ptr(tris), tris.shape[0], rand_calls_before, _ptr(out))
     if rc:
         raise RtError(f"rt_test_build_bvh failed ({rc})")
+    return out
+
+
+def tile_owner(nx: int, ny: int, world: int) -> np.ndarray:
+    """Which rank renders each pixel under tile sharding (RT_OPT_SHARD_*): (ny, nx) int32.  Needs no GPU."""
+    lib = load_library()
+    out = np.zeros((ny, nx), dtype=np.int32)
+    rc = lib.rt_test_tile_owner(nx, ny, world, _ptr(out))
+    if rc:
+        raise RtError(f"rt_test_tile_owner failed ({rc})")
     return out
 
 

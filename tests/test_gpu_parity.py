@@ -219,11 +219,37 @@ def test_tile_sharding_sums_to_the_frame():
             part = eng.render()
             total += eng.last_stats.rays
             owner_count += (part != 0).any(axis=2)
+            assert not (part[engine.tile_owner(nx, ny, world) != rank] != 0).any()  # only its own tiles are written
             acc += part  # x + 0 is exact, so the sum over ranks is bit-identical to the single-GPU frame
         assert acc.tobytes() == whole.tobytes(), world
         assert total == rays
         assert owner_count.max() == 1
     eng.close()
+
+
+def test_cpp_host_example(oracle, tmp_path):
+    """The C++ PbrtEngine shim (rt_amd/csrc/rt_engine.hpp) driven by examples/render_ppm.cpp, as the reference's
+    `render param nx ny ns` + `render` console commands would: its output.ppm equals the oracle's, byte for byte."""
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "render_ppm")
+    if not os.path.exists(exe):
+        pytest.fail("examples/render_ppm is not built: run __graft_entry__.build()")
+    nx, ny, ns = 96, 54, 5
+    out = subprocess.run([exe, str(nx), str(ny), str(ns)], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert f"rendering a {nx}[width]x{ny}[height] image with {ns} samples per pixel in 16x16 blocks." in out.stdout
+    assert "Total num of Triangles: 4" in out.stdout and "PbrtEngine: rendering finished." in out.stdout
+    v = np.array([[4, 10, -4], [-4, 10, -4], [-4, 10, 4], [4, 10, 4]], dtype=np.float32)
+    g = np.array([[-20, 0, -20], [-20, 0, 20], [20, 0, 20], [20, 0, -20]], dtype=np.float32)
+    tris = np.concatenate([scenes.make_triangles(v[[3, 3]], v[[2, 1]], v[[1, 0]], 3),
+                           scenes.make_triangles(g[[0]], g[[1]], g[[2]], 8), scenes.make_triangles(g[[0]], g[[2]], g[[3]], 9)])
+    nodes = oracle.build_bvh(tris)
+    cam = scenes.DEFAULT_CAMERA
+    ocam = oracle.camera(cam["lookfrom"], cam["lookat"], 40.0, nx / ny, 0.0, 10.0)
+    fb, _ = oracle.render(tris, nodes, oracle.material_table(), ocam, nx, ny, ns, 50, mode=0)
+    oracle.write_ppm(str(tmp_path / "ref.ppm"), fb)
+    assert (tmp_path / "output.ppm").read_bytes() == (tmp_path / "ref.ppm").read_bytes()
 
 
 def test_error_behaviour():
