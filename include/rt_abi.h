@@ -128,7 +128,10 @@ enum {
     RT_OPT_LDS_STACK = 10,       /* kernel 1: stack entries per lane kept in LDS (the rest spill to HBM) */
     RT_OPT_NODE_FORMAT = 11,     /* kernel 1/2: 0 = 128-byte float nodes, 1 = 64-byte quantized nodes (default) */
     RT_OPT_LEAF_BATCH = 12,      /* kernel 2: primitive tests run when this many lanes have a leaf pending */
-    RT_OPT_OCCUPANCY = 13        /* kernel 1/2, quantized nodes: waves per SIMD the registers are held to: 4, 6, 8 */
+    RT_OPT_OCCUPANCY = 13,       /* kernel 1/2, quantized nodes: waves per SIMD the registers are held to: 4, 6, 8 */
+    RT_OPT_TOPOLOGY = 14         /* device hierarchy: 0 = the reference's tree, wide-ified; 1 = a binned-SAH tree
+                                    re-built over the same primitives (default).  Results are identical;
+                                    rt_get_bvh_nodes always returns the reference's tree. */
 };
 int rt_set_option(rt_ctx *ctx, int option, int64_t value);
 int rt_get_option(rt_ctx *ctx, int option, int64_t *value);
@@ -161,7 +164,7 @@ int rt_test_build_bvh(const rt_triangle148 *tris, int n, int64_t rand_calls_befo
  * wide_nodes: 128 bytes each; quant_nodes: 64 bytes each (same indices); prims: 48 bytes each (DFS leaf order); info[4] = {n_wide, n_prims,
  * depth, stack_entries}. */
 int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size,
-                        int box_mode, void *wide_nodes, void *quant_nodes, void *prims, int32_t info[4]);
+                        int box_mode, int topology, void *wide_nodes, void *quant_nodes, void *prims, int32_t info[4]);
 
 /* The tile-sharding rule alone (no GPU needed): owner[j*nx+i] = rank that renders pixel (i, j) when the frame
  * is split over `world` contexts (RT_OPT_SHARD_RANK / RT_OPT_SHARD_WORLD). */

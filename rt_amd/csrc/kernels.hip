@@ -67,9 +67,11 @@ struct Hit {
 // Primitive test.  Triangle: Triangle::hit, include/RT/triangle.h:136-179 (Moeller-Trumbore, no
 // determinant epsilon, two-sided).  Sphere: triangle.h:180-213 (near root only; the "second root"
 // repeats the minus sign).  t interval is the reference's fixed (0.001, FLT_MAX).
-__device__ __forceinline__ bool prim_test(const float4 *__restrict__ prims, uint32_t rank, const Ray &r, float &t_out) {
+__device__ __forceinline__ bool prim_test(const float4 *__restrict__ prims, uint32_t rank, const Ray &r, float &t_out,
+                                          int &ref_rank) {
     const float4 *p = prims + 3 * (size_t)rank;
     float4 A = p[0], B = p[1], C = p[2];
+    ref_rank = __float_as_int(C.w);
     if (__float_as_int(C.y) == 0) {
         V3 v0 = mk(A.x, A.y, A.z), e1 = mk(A.w, B.x, B.y), e2 = mk(B.z, B.w, C.x);
         V3 tvec = vsub(r.o, v0);
@@ -102,6 +104,14 @@ __device__ __forceinline__ bool prim_test(const float4 *__restrict__ prims, uint
         }
         return false;
     }
+}
+
+// min t; ties go to the earlier DFS leaf of the REFERENCE tree (pbrt_engine.cu:421-438).  The tie branch is rare:
+// it re-reads the incumbent's reference rank instead of carrying it in a register.
+__device__ __forceinline__ bool better_hit(const float4 *__restrict__ prims, float t, int ref_rank, float best_t, int best_idx) {
+    if (t < best_t) return true;
+    if (t == best_t && best_idx != RT_NO_HIT) return ref_rank < __float_as_int(prims[3 * (size_t)best_idx + 2].w);
+    return false;
 }
 
 __device__ __forceinline__ float safe_inv(float d) {
@@ -185,12 +195,11 @@ __device__ __forceinline__ Hit closest_hit(const float4 *__restrict__ nodes, con
             const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
             for (uint32_t i = 0; i < cnt; i++) {
                 float t;
-                if (prim_test(prims, start + i, r, t)) {
-                    int rk = (int)(start + i);
-                    // min t; ties to the earlier DFS leaf (pbrt_engine.cu:421-438)
-                    if (t < best_t || (t == best_t && rk < best_rank)) {
+                int rr;
+                if (prim_test(prims, start + i, r, t, rr)) {
+                    if (better_hit(prims, t, rr, best_t, best_rank)) {
                         best_t = t;
-                        best_rank = rk;
+                        best_rank = (int)(start + i);
                     }
                 }
             }
@@ -301,12 +310,12 @@ __device__ __forceinline__ bool shade_bounce(const KernelScene &S, const Hit &h,
     }
     // hit record: p, face-forwarded normal (triangle.h:163-173) or sphere normal (:193)
     const float4 pc = S.prims[3 * (size_t)h.rank + 2];
+    const float4 sh = S.shade[h.rank];
     const int shape = __float_as_int(pc.y);
-    const int mat_id = __float_as_int(pc.w);
+    const int mat_id = __float_as_int(sh.w);
     V3 p = vadd(cur.o, vscl(h.t, cur.d));
     V3 n;
     if (shape == 0) {
-        const float4 sh = S.shade[h.rank];
         V3 gn = mk(sh.x, sh.y, sh.z);
         n = (vdot(cur.d, gn) < 0.0f) ? gn : vneg(gn);
     } else {
@@ -666,11 +675,11 @@ __device__ __forceinline__ void leaf_test(Trav &T, const KernelScene &S, const R
     const uint32_t cnt = ((ref >> 28) & 7u) + 1u;
     for (uint32_t i = 0; i < cnt; i++) {
         float t;
-        if (prim_test(S.prims, start + i, r, t)) {
-            int rk = (int)(start + i);
-            if (t < T.best_t || (t == T.best_t && rk < T.best_rank)) {
+        int rr;
+        if (prim_test(S.prims, start + i, r, t, rr)) {
+            if (better_hit(S.prims, t, rr, T.best_t, T.best_rank)) {
                 T.best_t = t;
-                T.best_rank = rk;
+                T.best_rank = (int)(start + i);
             }
         }
     }

@@ -16,6 +16,7 @@
 #include "kernels.h"
 #include "rt_shared_math.h"
 #include "rt_types.h"
+#include "sah_build.h"
 #include "wide_bvh.h"
 
 #pragma clang fp contract(off)
@@ -29,7 +30,7 @@ struct rt_ctx {
     // NX/NY/NS, include/RT/pbrt_engine.h:24-26 ; ITER_NUM, pbrt_engine.cu:458
     int nx = 640, ny = 360, ns = 10, max_depth = 50;
     int honor_vfov = 0, leaf_size = 1, box_mode = 0, shard_rank = 0, shard_world = 1, kernel_variant = 1;
-    int refill_threshold = 48, waves_per_cu = 24, lds_stack = 16, node_format = 1, leaf_batch = 8, occupancy = 6;
+    int refill_threshold = 48, waves_per_cu = 24, lds_stack = 16, node_format = 1, leaf_batch = 8, occupancy = 6, topology = 1;
     int n_cus = 256;
     unsigned int *d_bands = nullptr;
     uint32_t *d_spill = nullptr;
@@ -124,10 +125,25 @@ void free_scene(rt_ctx *c) {
     c->scene_on_device = false;
 }
 
+// device layout from the reference tree (topology 0) or from a re-built SAH tree over the same primitives
+// (topology 1); either way ties are broken by the DFS-leaf rank in the REFERENCE tree.
+bool make_device_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *ref_nodes, int m, int leaf_size,
+                        int box_mode, int topology, WideBvh &wide, std::string &err) {
+    if (topology == 0) return build_wide_bvh(tris, n, ref_nodes, m, leaf_size, box_mode, nullptr, wide, err);
+    std::vector<int32_t> order;
+    if (!dfs_leaf_order(ref_nodes, m, n, order, err)) return false;
+    std::vector<int32_t> ref_rank(n);
+    for (int r = 0; r < n; r++) ref_rank[order[r]] = r;
+    std::vector<rt_bvh_node32> sah;
+    build_sah_bvh(tris, n, sah);
+    // the SAH nodes carry un-padded boxes: always re-fit + pad (box mode 0)
+    return build_wide_bvh(tris, n, sah.data(), (int)sah.size(), leaf_size, 0, ref_rank.data(), wide, err);
+}
+
 int upload_scene(rt_ctx *c) {
     std::string err;
-    if (!build_wide_bvh(c->tris.data(), (int)c->tris.size(), c->bnodes.data(), (int)c->bnodes.size(), c->leaf_size,
-                        c->box_mode, c->wide, err))
+    if (!make_device_layout(c->tris.data(), (int)c->tris.size(), c->bnodes.data(), (int)c->bnodes.size(), c->leaf_size,
+                            c->box_mode, c->topology, c->wide, err))
         return fail(c, RT_E_ARG, "wide BVH: " + err);
     if ((size_t)c->wide.stack_entries * 64 * 4 > 64 * 1024) return fail(c, RT_E_LIMIT, "tree too deep for the LDS stack");
     free_scene(c);
@@ -481,6 +497,11 @@ int rt_set_option(rt_ctx *c, int option, int64_t value) {
         if (value != 4 && value != 6 && value != 8) return fail(c, RT_E_ARG, "occupancy 4, 6 or 8");
         c->occupancy = (int)value;
         return RT_OK;
+    case RT_OPT_TOPOLOGY:
+        if (value != 0 && value != 1) return fail(c, RT_E_ARG, "topology 0 or 1");
+        if (c->topology != (int)value) c->scene_on_device = false;
+        c->topology = (int)value;
+        return RT_OK;
     default:
         return fail(c, RT_E_ARG, "unknown option");
     }
@@ -502,6 +523,7 @@ int rt_get_option(rt_ctx *c, int option, int64_t *value) {
     case RT_OPT_NODE_FORMAT: *value = c->node_format; return RT_OK;
     case RT_OPT_LEAF_BATCH: *value = c->leaf_batch; return RT_OK;
     case RT_OPT_OCCUPANCY: *value = c->occupancy; return RT_OK;
+    case RT_OPT_TOPOLOGY: *value = c->topology; return RT_OK;
     default: return fail(c, RT_E_ARG, "unknown option");
     }
 }
@@ -690,11 +712,11 @@ int rt_test_build_bvh(const rt_triangle148 *tris, int n, int64_t rand_calls_befo
 }
 
 int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size,
-                        int box_mode, void *wide_nodes, void *quant_nodes, void *prims, int32_t info[4]) {
+                        int box_mode, int topology, void *wide_nodes, void *quant_nodes, void *prims, int32_t info[4]) {
     if (!tris || !nodes || !info) return RT_E_ARG;
     WideBvh w;
     std::string err;
-    if (!build_wide_bvh(tris, n, nodes, m, leaf_size, box_mode, w, err)) return RT_E_ARG;
+    if (!make_device_layout(tris, n, nodes, m, leaf_size, box_mode, topology, w, err)) return RT_E_ARG;
     info[0] = (int32_t)w.nodes.size();
     info[1] = (int32_t)w.prims.size();
     info[2] = w.depth;

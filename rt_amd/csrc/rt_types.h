@@ -39,18 +39,18 @@ constexpr uint32_t kEmptyRef = 0xFFFFFFFFu; // unused slot (its box is inverted 
 constexpr uint32_t kLeafStartMask = 0x0FFFFFFFu;
 constexpr int kMaxLeafPrims = 8;
 
-// ---- primitive record used by the intersection test: 48 bytes, in DFS leaf order ----
-// (so that "earlier DFS leaf wins a tie", reference pbrt_engine.cu:421-438, is "lower index wins")
+// ---- primitive record used by the intersection test: 48 bytes, in DFS leaf order of the DEVICE tree ----
+// ("earlier DFS leaf wins a tie", reference pbrt_engine.cu:421-438, is "lower ref_rank wins")
 //   a = (v0.x, v0.y, v0.z, e1.x)      sphere: centre, radius
 //   b = (e1.y, e1.z, e2.x, e2.y)
-//   c = (e2.z, shape (0 tri / 1 sphere), original index, material)
+//   c = (e2.z, shape (0 tri / 1 sphere), original index, DFS-leaf rank in the REFERENCE tree = tie-break order)
 struct DevPrim {
     float a[4];
     float b[4];
     float e2z;
     int32_t shape;
     int32_t orig;
-    int32_t mat;
+    int32_t ref_rank;
 };
 static_assert(sizeof(DevPrim) == 48, "DevPrim must be 48 bytes");
 

@@ -25,8 +25,46 @@ inline float half_area(const Info &b) {
 
 } // namespace
 
+bool dfs_leaf_order(const rt_bvh_node32 *nodes, int m, int n, std::vector<int32_t> &order, std::string &err) {
+    order.clear();
+    if (n <= 0 || m != 2 * n - 1) {
+        err = "node count must be 2*n-1";
+        return false;
+    }
+    order.reserve(n);
+    std::vector<uint8_t> seen(m, 0), prim_seen(n, 0);
+    std::vector<int32_t> stk;
+    stk.push_back(m - 1);
+    while (!stk.empty()) {
+        int32_t c = stk.back();
+        stk.pop_back();
+        if (c < 0 || c >= m || seen[c]) {
+            err = "node index out of range or reached twice: not a tree";
+            return false;
+        }
+        seen[c] = 1;
+        const rt_bvh_node32 &nd = nodes[c];
+        if (nd.left == nd.right) {
+            if (nd.left < 0 || nd.left >= n || prim_seen[nd.left]) {
+                err = "leaf primitive index out of range or repeated";
+                return false;
+            }
+            prim_seen[nd.left] = 1;
+            order.push_back(nd.left);
+        } else {
+            stk.push_back(nd.right);
+            stk.push_back(nd.left);
+        }
+    }
+    if ((int)order.size() != n) {
+        err = "tree does not cover every primitive";
+        return false;
+    }
+    return true;
+}
+
 bool build_wide_bvh(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size, int box_mode,
-                    WideBvh &out, std::string &err) {
+                    const int32_t *ref_rank, WideBvh &out, std::string &err) {
     out = WideBvh();
     if (n <= 0 || m <= 0) {
         err = "empty scene";
@@ -119,7 +157,7 @@ bool build_wide_bvh(const rt_triangle148 *tris, int n, const rt_bvh_node32 *node
             s.normal[0] = s.normal[1] = s.normal[2] = 0.0f;
         }
         p.orig = order[r];
-        p.mat = t.matType;
+        p.ref_rank = ref_rank ? ref_rank[order[r]] : r;
         s.mat = t.matType;
     }
 

@@ -23,7 +23,12 @@ struct WideBvh {
 
 // leaf_size: 1..kMaxLeafPrims primitives per leaf.  box_mode: 0 = re-fitted + one pad, 1 = reference boxes.
 // Returns false and fills err if the node array is not a tree over exactly the n primitives.
+// ref_rank: per primitive, its DFS-leaf rank in the reference tree (tie order); nullptr = the rank in `nodes` itself.
 bool build_wide_bvh(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size, int box_mode,
-                    WideBvh &out, std::string &err);
+                    const int32_t *ref_rank, WideBvh &out, std::string &err);
+
+// DFS (left first) leaf order of a binary tree: order[rank] = primitive.  Validates that `nodes` is a tree over
+// exactly the n primitives.
+bool dfs_leaf_order(const rt_bvh_node32 *nodes, int m, int n, std::vector<int32_t> &order, std::string &err);
 
 } // namespace rtamd

@@ -36,7 +36,7 @@ assert MAT_DTYPE.itemsize == 20
 
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_LIGHT = 0, 1, 2, 3
 OPT_MAX_DEPTH, OPT_HONOR_VFOV, OPT_LEAF_SIZE, OPT_BOX_MODE, OPT_SHARD_RANK, OPT_SHARD_WORLD, OPT_KERNEL = 1, 2, 3, 4, 5, 6, 7
-OPT_REFILL_THRESHOLD, OPT_WAVES_PER_CU, OPT_LDS_STACK, OPT_NODE_FORMAT, OPT_LEAF_BATCH, OPT_OCCUPANCY = 8, 9, 10, 11, 12, 13
+OPT_REFILL_THRESHOLD, OPT_WAVES_PER_CU, OPT_LDS_STACK, OPT_NODE_FORMAT, OPT_LEAF_BATCH, OPT_OCCUPANCY, OPT_TOPOLOGY = 8, 9, 10, 11, 12, 13, 14
 
 
 class RtStats(C.Structure):
@@ -99,7 +99,7 @@ def load_library(path: str = LIB_PATH):
     lib.rt_test_introsort.argtypes = [vp, vp, C.c_int]
     lib.rt_test_build_bvh.argtypes = [vp, C.c_int, C.c_int64, vp]
     lib.rt_test_tile_owner.argtypes = [C.c_int, C.c_int, C.c_int, vp]
-    lib.rt_test_wide_layout.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.rt_test_wide_layout.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     for name in ABI_SYMBOLS:
         if name != "rt_last_error":
             getattr(lib, name).restype = C.c_int
@@ -144,24 +144,25 @@ def tile_owner(nx: int, ny: int, world: int) -> np.ndarray:
 
 WIDE_DTYPE = np.dtype([("plane", "<f4", (6, 4)), ("child", "<u4", 4), ("aux", "<u4", 4)])
 QUANT_DTYPE = np.dtype([("origin", "<f4", 3), ("exps", "<u4"), ("q", "<u4", 6), ("pad", "<u4", 2), ("child", "<u4", 4)])
-PRIM_DTYPE = np.dtype([("a", "<f4", 4), ("b", "<f4", 4), ("e2z", "<f4"), ("shape", "<i4"), ("orig", "<i4"), ("mat", "<i4")])
+PRIM_DTYPE = np.dtype([("a", "<f4", 4), ("b", "<f4", 4), ("e2z", "<f4"), ("shape", "<i4"), ("orig", "<i4"), ("ref_rank", "<i4")])
 
 
-def host_wide_layout(tris: np.ndarray, nodes: np.ndarray, leaf_size: int = 1, box_mode: int = 0, quant: bool = False):
+def host_wide_layout(tris: np.ndarray, nodes: np.ndarray, leaf_size: int = 1, box_mode: int = 0, quant: bool = False,
+                     topology: int = 0):
     """The device layout alone (wide nodes, re-ordered primitives, depth, stack entries); needs no GPU."""
     lib = load_library()
     tris = np.ascontiguousarray(tris, dtype=TRI_DTYPE)
     nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
     info = np.zeros(4, dtype=np.int32)
-    rc = lib.rt_test_wide_layout(_ptr(tris), tris.shape[0], _ptr(nodes), nodes.shape[0], leaf_size, box_mode, None, None,
-                                 None, _ptr(info))
+    rc = lib.rt_test_wide_layout(_ptr(tris), tris.shape[0], _ptr(nodes), nodes.shape[0], leaf_size, box_mode, topology, None,
+                                 None, None, _ptr(info))
     if rc:
         raise RtError(f"rt_test_wide_layout failed ({rc})")
     wide = np.zeros(int(info[0]), dtype=WIDE_DTYPE)
     prims = np.zeros(int(info[1]), dtype=PRIM_DTYPE)
     qn = np.zeros(int(info[0]), dtype=QUANT_DTYPE)
-    rc = lib.rt_test_wide_layout(_ptr(tris), tris.shape[0], _ptr(nodes), nodes.shape[0], leaf_size, box_mode, _ptr(wide),
-                                 _ptr(qn), _ptr(prims), _ptr(info))
+    rc = lib.rt_test_wide_layout(_ptr(tris), tris.shape[0], _ptr(nodes), nodes.shape[0], leaf_size, box_mode, topology,
+                                 _ptr(wide), _ptr(qn), _ptr(prims), _ptr(info))
     if rc:
         raise RtError(f"rt_test_wide_layout failed ({rc})")
     if quant:

@@ -149,28 +149,29 @@ def test_trace_rays_incoherent(oracle):
     eng.close()
 
 
-@pytest.mark.parametrize("leaf,box_mode", [(1, 0), (2, 1), (8, 0), (4, 1)])
-def test_device_layout_options_do_not_change_results(leaf, box_mode):
+@pytest.mark.parametrize("leaf,box_mode,topo", [(1, 0, 0), (2, 1, 0), (8, 0, 0), (4, 1, 0), (4, 0, 1), (2, 1, 1)])
+def test_device_layout_options_do_not_change_results(leaf, box_mode, topo):
     tris = scenes.heightfield(40)
     base = _engine(tris, 96, 54, 3, 8, scenes.BENCH_CAMERA)
     want = base.render()
     want_ids, want_t = base.tracePrimary()
     base.close()
-    eng = _engine(tris, 96, 54, 3, 8, scenes.BENCH_CAMERA, {engine.OPT_LEAF_SIZE: leaf, engine.OPT_BOX_MODE: box_mode})
+    eng = _engine(tris, 96, 54, 3, 8, scenes.BENCH_CAMERA, {engine.OPT_LEAF_SIZE: leaf, engine.OPT_BOX_MODE: box_mode, engine.OPT_TOPOLOGY: topo})
     assert eng.render().tobytes() == want.tobytes()
     ids, ts = eng.tracePrimary()
     assert ids.tobytes() == want_ids.tobytes() and ts.tobytes() == want_t.tobytes()
     eng.close()
 
 
-@pytest.mark.parametrize("kernel,fmt,thr,batch,lds", [(0, 0, 40, 24, 16), (1, 0, 40, 24, 16), (1, 1, 64, 24, 2), (2, 0, 16, 1, 16),
-                                                     (2, 1, 48, 64, 4), (2, 1, 1, 8, 64)])
-def test_kernel_variants_bit_exact(oracle, kernel, fmt, thr, batch, lds):
+@pytest.mark.parametrize("kernel,fmt,thr,batch,lds,topo", [(0, 0, 40, 24, 16, 0), (1, 0, 40, 24, 16, 0), (1, 1, 64, 24, 2, 0),
+                                                          (2, 0, 16, 1, 16, 0), (2, 1, 48, 64, 4, 0), (2, 1, 1, 8, 64, 1),
+                                                          (0, 0, 40, 24, 16, 1), (1, 1, 48, 8, 3, 1), (1, 0, 32, 8, 16, 1)])
+def test_kernel_variants_bit_exact(oracle, kernel, fmt, thr, batch, lds, topo):
     """Every kernel variant (one wave per tile / persistent refill / speculative), node format (float /
     quantized), refill threshold, leaf batch and LDS-stack size (small ones force the HBM spill path) returns the
     oracle's image and hit ids, bit for bit."""
     opts = {engine.OPT_KERNEL: kernel, engine.OPT_NODE_FORMAT: fmt, engine.OPT_REFILL_THRESHOLD: thr,
-            engine.OPT_LEAF_BATCH: batch, engine.OPT_LDS_STACK: lds, engine.OPT_WAVES_PER_CU: 3}
+            engine.OPT_LEAF_BATCH: batch, engine.OPT_LDS_STACK: lds, engine.OPT_WAVES_PER_CU: 3, engine.OPT_TOPOLOGY: topo}
     for tris, cam, nx, ny, ns, depth in ((scenes.heightfield(50), scenes.BENCH_CAMERA, 150, 85, 4, 8),
                                          (scenes.spheres_scene(), scenes.DEFAULT_CAMERA, 90, 50, 3, 30)):
         eng = _engine(tris, nx, ny, ns, depth, cam, opts)

@@ -152,16 +152,18 @@ def _py_closest(wide, prims, org, d):
     return best, best_t
 
 
-@pytest.mark.parametrize("leaf,box_mode", [(1, 0), (4, 0), (8, 0), (4, 1), (2, 1)])
-def test_wide_layout_covers_and_hits(oracle, leaf, box_mode):
+@pytest.mark.parametrize("leaf,box_mode,topology", [(1, 0, 0), (4, 0, 0), (8, 0, 0), (4, 1, 0), (2, 1, 0), (1, 0, 1), (4, 0, 1)])
+def test_wide_layout_covers_and_hits(oracle, leaf, box_mode, topology):
     for tris, lo, hi in ((scenes.heightfield(14), (-9, 3, -9), (9, 8, 9)), (scenes.spheres_scene(), (-8, 0.5, -8), (8, 6, 8))):
         nodes = engine.host_build_bvh(tris)
-        wide, prims, depth, stack_entries = engine.host_wide_layout(tris, nodes, leaf, box_mode)
+        wide, prims, depth, stack_entries = engine.host_wide_layout(tris, nodes, leaf, box_mode, topology=topology)
         n = tris.shape[0]
         assert prims.shape[0] == n and sorted(prims["orig"].tolist()) == list(range(n))
-        # DFS leaf order of the binary tree
+        # tie order = DFS leaf rank in the REFERENCE tree; with the reference topology it is also the device order
         rank = oracle.dfs_rank(nodes, n)
-        assert (rank[prims["orig"]] == np.arange(n)).all()
+        assert (rank[prims["orig"]] == prims["ref_rank"]).all()
+        if topology == 0:
+            assert (prims["ref_rank"] == np.arange(n)).all()
         # every leaf range is referenced exactly once; every node but the root exactly once
         seen = np.zeros(n, dtype=np.int32)
         node_refs = np.zeros(wide.shape[0], dtype=np.int32)

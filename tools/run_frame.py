@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--fmt", type=ints, default=[1])
     ap.add_argument("--batch", type=ints, default=[8])
     ap.add_argument("--occ", type=ints, default=[6])
+    ap.add_argument("--topo", type=ints, default=[1])
     args = ap.parse_args()
     tris = scenes.heightfield(args.grid)
     eng = rt_amd.PbrtEngine(args.nx, args.ny, args.spp, device=0)
@@ -42,7 +43,7 @@ def main():
     eng.setMaxDepth(args.depth)
     eng.setCamera(**scenes.BENCH_CAMERA)
     nodes = None
-    for leaf, bm, kv, th, wv, ld, fm, lb, oc in itertools.product(args.leaf, args.box_mode, args.kernel, args.threshold, args.waves, args.lds, args.fmt, args.batch, args.occ):
+    for leaf, bm, kv, th, wv, ld, fm, lb, oc, tp in itertools.product(args.leaf, args.box_mode, args.kernel, args.threshold, args.waves, args.lds, args.fmt, args.batch, args.occ, args.topo):
         eng.setOption(E.OPT_LEAF_SIZE, leaf)
         eng.setOption(E.OPT_BOX_MODE, bm)
         eng.setOption(E.OPT_KERNEL, kv)
@@ -52,12 +53,13 @@ def main():
         eng.setOption(E.OPT_NODE_FORMAT, fm)
         eng.setOption(E.OPT_LEAF_BATCH, lb)
         eng.setOption(E.OPT_OCCUPANCY, oc)
+        eng.setOption(E.OPT_TOPOLOGY, tp)
         if nodes is None:
             eng.buildBvh()
             nodes = eng.getBvhNodes()
         else:
             eng.setBvhNodes(nodes)
-        out = {"leaf": leaf, "box_mode": bm, "kernel": kv, "thr": th, "waves": wv, "lds": ld, "fmt": fm, "batch": lb, "occ": oc}
+        out = {"leaf": leaf, "box_mode": bm, "kernel": kv, "thr": th, "waves": wv, "lds": ld, "fmt": fm, "batch": lb, "occ": oc, "topo": tp}
         best = None
         for _ in range(args.frames):
             eng.render()
