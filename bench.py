@@ -179,7 +179,7 @@ def main():
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "kernel": "k_persistent<0,1,0,6> (render, quantized nodes)", "kernel_ms": kernel_s * 1e3,
+                    "traffic": traffic, "kernel": "k_persistent<0,1,1,6> (render, quantized nodes, speculative)", "kernel_ms": kernel_s * 1e3,
                     "algorithmic_bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_launch}
         line = {
             "metric": "Mrays/s (node) on 1M-tri BVH; ms/frame at 1080p",

@@ -116,7 +116,7 @@ int rt_set_camera(rt_ctx *ctx, const float lookfrom[3], const float lookat[3], f
 enum {
     RT_OPT_MAX_DEPTH = 1,   /* ITER_NUM, pbrt_engine.cu:458 (default 50) */
     RT_OPT_HONOR_VFOV = 2,  /* default 0 */
-    RT_OPT_LEAF_SIZE = 3,   /* primitives per device leaf, 1..8 (default 1); applies at next build */
+    RT_OPT_LEAF_SIZE = 3,   /* primitives per device leaf, 1..8 (default 2); applies at next build */
     RT_OPT_BOX_MODE = 4,    /* 0 = re-fitted boxes + one small pad (default), 1 = the reference's
                                cumulatively padded boxes (triangle.h:28-31,76-85) */
     RT_OPT_SHARD_RANK = 5,  /* multi-GPU tile sharding: this context renders the 8x8 tiles with */

@@ -29,8 +29,8 @@ struct rt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // NX/NY/NS, include/RT/pbrt_engine.h:24-26 ; ITER_NUM, pbrt_engine.cu:458
     int nx = 640, ny = 360, ns = 10, max_depth = 50;
-    int honor_vfov = 0, leaf_size = 1, box_mode = 0, shard_rank = 0, shard_world = 1, kernel_variant = 1;
-    int refill_threshold = 48, waves_per_cu = 24, lds_stack = 16, node_format = 1, leaf_batch = 8, occupancy = 6, topology = 1;
+    int honor_vfov = 0, leaf_size = 2, box_mode = 0, shard_rank = 0, shard_world = 1, kernel_variant = 2;
+    int refill_threshold = 32, waves_per_cu = 24, lds_stack = 16, node_format = 1, leaf_batch = 16, occupancy = 6, topology = 1;
     int n_cus = 256;
     unsigned int *d_bands = nullptr;
     uint32_t *d_spill = nullptr;

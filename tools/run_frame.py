@@ -26,14 +26,14 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--frames", type=int, default=1)
     ap.add_argument("--primary", type=int, default=1)
-    ap.add_argument("--leaf", type=ints, default=[1])
+    ap.add_argument("--leaf", type=ints, default=[2])
     ap.add_argument("--box-mode", type=ints, default=[0])
-    ap.add_argument("--kernel", type=ints, default=[1])
-    ap.add_argument("--threshold", type=ints, default=[48])
+    ap.add_argument("--kernel", type=ints, default=[2])
+    ap.add_argument("--threshold", type=ints, default=[32])
     ap.add_argument("--waves", type=ints, default=[24])
     ap.add_argument("--lds", type=ints, default=[16])
     ap.add_argument("--fmt", type=ints, default=[1])
-    ap.add_argument("--batch", type=ints, default=[8])
+    ap.add_argument("--batch", type=ints, default=[16])
     ap.add_argument("--occ", type=ints, default=[6])
     ap.add_argument("--topo", type=ints, default=[1])
     args = ap.parse_args()
