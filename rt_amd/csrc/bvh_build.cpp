@@ -2,7 +2,10 @@
 #include "bvh_build.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <unordered_map>
 
 namespace rtamd {
 
@@ -224,14 +227,33 @@ void prim_box_padded(const rt_triangle148 &t, float mn[3], float mx[3]) {
 // ---------------------------------------------------------------- make_bvh_nodes
 namespace {
 
+// Number of make_bvh_nodes invocations (= rand() calls) a subtree of cnt primitives makes.  It depends on cnt
+// alone, so every subtree's position in the rand() sequence -- and, because a subtree of cnt primitives always emits
+// 2*cnt-1 nodes, its position in the post-order node array -- is known before it is built.  That is what lets
+// sibling subtrees be built concurrently with a bit-identical result ("Scale").
+struct CallCount {
+    std::unordered_map<int, int64_t> memo;
+    int64_t operator()(int cnt) {
+        if (cnt <= 2) return 1;
+        auto it = memo.find(cnt);
+        if (it != memo.end()) return it->second;
+        int64_t v = 1 + (*this)(cnt / 2) + (*this)(cnt - cnt / 2);
+        memo[cnt] = v;
+        return v;
+    }
+    int64_t get(int cnt) const { // after the root's count has been evaluated every reachable size is in the memo
+        if (cnt <= 2) return 1;
+        return memo.find(cnt)->second;
+    }
+};
+
 struct Builder {
     const float *key[3]; // padded box min per axis, per primitive (what X/Y/Z_CMP compare, triangle.h:394-434)
     const float *pmn, *pmx; // padded boxes, 3 floats per primitive
     std::vector<int32_t> order;
-    std::vector<rt_bvh_node32> *out;
-    GlibcRand rng;
-
-    explicit Builder(uint32_t seed) : rng(seed) {}
+    rt_bvh_node32 *out = nullptr;
+    std::vector<uint8_t> axis_of_call; // axis = int(3 * drand48()) for every rand() call of the build, in order
+    int par_depth = 0;                 // subtrees above this depth are built on their own threads
 
     rt_bvh_node32 leaf(int32_t prim) const {
         rt_bvh_node32 nd;
@@ -244,7 +266,7 @@ struct Builder {
         return nd;
     }
     rt_bvh_node32 parent(int32_t l, int32_t r) const {
-        const rt_bvh_node32 &a = (*out)[l], &b = (*out)[r];
+        const rt_bvh_node32 &a = out[l], &b = out[r];
         rt_bvh_node32 nd;
         for (int k = 0; k < 3; k++) { // surrounding_box, triangle.h:76-85: union, then padded AGAIN by the ctor
             nd.box_min[k] = std::fmin(a.box_min[k], b.box_min[k]) + (-kShift);
@@ -254,26 +276,32 @@ struct Builder {
         nd.right = r;
         return nd;
     }
-    void go(int m, int n) {
-        float dr = (float)rng.next() / (float)2147483647; // rand() / (float)RAND_MAX
-        int axis = (int)(3 * dr);
-        const float *k = axis == 0 ? key[0] : (axis == 1 ? key[1] : key[2]); // axis 3 (dr == 1) -> z, as the else branch
+    // make_bvh_nodes(_p, m, n, ...), pbrt_engine.cu:335-368.  call = index of this invocation's rand() call;
+    // base = index of the first node this subtree emits.
+    void go(int m, int n, int64_t call, int64_t base, int depth, const CallCount *calls) {
+        int axis = axis_of_call[(size_t)call];
+        const float *k = axis == 0 ? key[0] : (axis == 1 ? key[1] : key[2]); // axis 3 -> z, as the else branch
         introsort_by_key(k, order.data() + m, n - m);
         int cnt = n - m;
         if (cnt == 1) {
-            out->push_back(leaf(order[m]));
+            out[base] = leaf(order[m]);
         } else if (cnt == 2) {
-            int32_t i1 = (int32_t)out->size();
-            int32_t i2 = i1 + 1;
-            out->push_back(leaf(order[m]));
-            out->push_back(leaf(order[m + 1]));
-            out->push_back(parent(i1, i2));
+            out[base] = leaf(order[m]);
+            out[base + 1] = leaf(order[m + 1]);
+            out[base + 2] = parent((int32_t)base, (int32_t)base + 1);
         } else if (cnt != 0) {
-            go(m, m + cnt / 2);
-            int32_t i1 = (int32_t)out->size() - 1;
-            go(m + cnt / 2, n);
-            int32_t i2 = (int32_t)out->size() - 1;
-            out->push_back(parent(i1, i2));
+            const int l = cnt / 2;
+            const int64_t lcalls = calls->get(l);
+            const int64_t rbase = base + 2 * (int64_t)l - 1;
+            if (depth < par_depth) {
+                std::thread left([=]() { go(m, m + l, call + 1, base, depth + 1, calls); });
+                go(m + l, n, call + 1 + lcalls, rbase, depth + 1, calls);
+                left.join();
+            } else {
+                go(m, m + l, call + 1, base, depth + 1, calls);
+                go(m + l, n, call + 1 + lcalls, rbase, depth + 1, calls);
+            }
+            out[base + 2 * (int64_t)cnt - 2] = parent((int32_t)(rbase - 1), (int32_t)(base + 2 * (int64_t)cnt - 3));
         }
     }
 };
@@ -291,8 +319,18 @@ void build_binary_bvh(const rt_triangle148 *tris, int n, int64_t rand_calls_befo
         ky[i] = pmn[3 * (size_t)i + 1];
         kz[i] = pmn[3 * (size_t)i + 2];
     }
-    Builder b(1); // rand() is never seeded by the reference: default state == srand(1)
-    for (int64_t i = 0; i < rand_calls_before; i++) (void)b.rng.next();
+    Builder b;
+    CallCount calls;
+    const int64_t total_calls = calls(n);
+    {
+        GlibcRand rng(1); // rand() is never seeded by the reference: default state == srand(1)
+        for (int64_t i = 0; i < rand_calls_before; i++) (void)rng.next();
+        b.axis_of_call.resize((size_t)total_calls);
+        for (int64_t i = 0; i < total_calls; i++) {
+            float dr = (float)rng.next() / (float)2147483647; // rand() / (float)RAND_MAX, triangle.h:12-15
+            b.axis_of_call[(size_t)i] = (uint8_t)(int)(3 * dr);
+        }
+    }
     b.key[0] = kx.data();
     b.key[1] = ky.data();
     b.key[2] = kz.data();
@@ -300,9 +338,11 @@ void build_binary_bvh(const rt_triangle148 *tris, int n, int64_t rand_calls_befo
     b.pmx = pmx.data();
     b.order.resize(n);
     for (int i = 0; i < n; i++) b.order[i] = i;
-    out.reserve(2 * (size_t)n);
-    b.out = &out;
-    b.go(0, n);
+    out.resize(2 * (size_t)n - 1);
+    b.out = out.data();
+    b.par_depth = n >= (1 << 15) && std::thread::hardware_concurrency() > 1 ? 4 : 0; // 16 concurrent subtrees
+    if (const char *e = std::getenv("RT_BUILD_PAR_DEPTH")) b.par_depth = std::atoi(e);
+    b.go(0, n, 0, 0, 0, &calls);
 }
 
 } // namespace rtamd

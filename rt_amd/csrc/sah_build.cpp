@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <thread>
 
 #include "bvh_build.h"
 
@@ -44,23 +45,26 @@ struct Sah {
     const std::vector<Box3> &box;
     const std::vector<float> &cen; // 3 per primitive
     std::vector<int32_t> idx;
-    std::vector<rt_bvh_node32> *out;
+    rt_bvh_node32 *out = nullptr;
+    int par_depth = 0;
 
     Sah(const std::vector<Box3> &b, const std::vector<float> &c) : box(b), cen(c) {}
 
-    int32_t emit_leaf(int32_t prim) {
+    int32_t emit_leaf(int32_t prim, int64_t base) {
         rt_bvh_node32 nd;
         for (int a = 0; a < 3; a++) {
             nd.box_min[a] = box[prim].mn[a];
             nd.box_max[a] = box[prim].mx[a];
         }
         nd.left = nd.right = prim;
-        out->push_back(nd);
-        return (int32_t)out->size() - 1;
+        out[base] = nd;
+        return (int32_t)base;
     }
 
-    int32_t build(int lo, int hi, int depth) {
-        if (hi - lo == 1) return emit_leaf(idx[lo]);
+    // A subtree over cnt primitives always emits 2*cnt-1 nodes (post-order: left subtree, right subtree, parent),
+    // so its slots [base, base + 2*cnt - 1) are known up front and sibling subtrees can be built concurrently.
+    int32_t build(int lo, int hi, int depth, int64_t base) {
+        if (hi - lo == 1) return emit_leaf(idx[lo], base);
         Box3 cb, bb;
         cb.reset();
         bb.reset();
@@ -140,8 +144,16 @@ struct Sah {
                 return cp < cq || (cp == cq && p < q);
             });
         }
-        int32_t l = build(lo, mid, depth + 1);
-        int32_t r = build(mid, hi, depth + 1);
+        const int64_t rbase = base + 2 * (int64_t)(mid - lo) - 1;
+        int32_t l, r;
+        if (depth < par_depth) {
+            std::thread left([&]() { l = build(lo, mid, depth + 1, base); });
+            r = build(mid, hi, depth + 1, rbase);
+            left.join();
+        } else {
+            l = build(lo, mid, depth + 1, base);
+            r = build(mid, hi, depth + 1, rbase);
+        }
         rt_bvh_node32 nd;
         for (int a = 0; a < 3; a++) {
             nd.box_min[a] = bb.mn[a];
@@ -149,8 +161,9 @@ struct Sah {
         }
         nd.left = l;
         nd.right = r;
-        out->push_back(nd);
-        return (int32_t)out->size() - 1;
+        const int64_t self = base + 2 * (int64_t)(hi - lo) - 2;
+        out[self] = nd;
+        return (int32_t)self;
     }
 };
 
@@ -168,9 +181,10 @@ void build_sah_bvh(const rt_triangle148 *tris, int n, std::vector<rt_bvh_node32>
     Sah s(box, cen);
     s.idx.resize(n);
     for (int i = 0; i < n; i++) s.idx[i] = i;
-    out.reserve(2 * (size_t)n);
-    s.out = &out;
-    s.build(0, n, 0);
+    out.resize(2 * (size_t)n - 1);
+    s.out = out.data();
+    s.par_depth = n >= (1 << 15) && std::thread::hardware_concurrency() > 1 ? 4 : 0;
+    s.build(0, n, 0, 0);
 }
 
 } // namespace rtamd
