@@ -794,7 +794,9 @@ void o_material_table(o_mat out[50]) { /* material_init, pbrt_engine.cu:25-47 */
     }
 }
 
-int o_build_bvh(const o_tri148 *tris, int n, o_node32 *out) {
+int o_build_bvh(const o_tri148 *tris, int n, o_node32 *out) { return o_build_bvh_after(tris, n, 0, out); }
+
+int o_build_bvh_after(const o_tri148 *tris, int n, long long rand_calls_before, o_node32 *out) {
     /* __genBvhNodes + make_bvh_nodes(vector version), pbrt_engine.cu:181-197,335-368.
      * rand() in its default state == srand(1) (triangle.h:12-15 never seeds it). */
     struct Item {
@@ -808,6 +810,8 @@ int o_build_bvh(const o_tri148 *tris, int n, o_node32 *out) {
     std::vector<o_node32> nodes;
     nodes.reserve(2 * (size_t)n);
     srand(1);
+    /* the caller's process had already drawn this many numbers (scene setup, main.cpp:449-474; earlier builds) */
+    for (long long i = 0; i < rand_calls_before; i++) (void)rand();
     auto leaf = [&](const Item &it) {
         Box b = tri_box(*it.p);
         o_node32 nd;

@@ -90,6 +90,9 @@ void o_material_table(o_mat out[50]);
 /* -- make_bvh_nodes, pbrt_engine.cu:335-368; srand(1) (= glibc default state) first.
  *    out must hold 2n-1 nodes.  returns node count. -- */
 int o_build_bvh(const o_tri148 *tris, int n, o_node32 *out);
+/* same, with rand() advanced by rand_calls_before draws first (the reference shares the unseeded rand() between
+ * scene setup, main.cpp:449-474, and every build of a session) */
+int o_build_bvh_after(const o_tri148 *tris, int n, long long rand_calls_before, o_node32 *out);
 
 /* -- camera::update, rt_camera.h:37-52 (vfov is what the caller passes; the
  *    reference's camera_update kernel always passes 40, pbrt_engine.cu:629) -- */

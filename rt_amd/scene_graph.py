@@ -1,0 +1,268 @@
+"""Scene flattening without GL: the step immediately before the trace loop.
+
+Restates, in float32 numpy, the parts of the reference's host scene code that decide the kernel's input:
+
+* ``Mesh`` / ``FlyWeight`` transforms and ``Mesh::genTriangles`` (reference include/RT/mesh.h:253-291, 591-622;
+  src/cxx/mesh.cpp:119-156): model = translate . rotation . uniform scale (glm, column-major, float32); a mesh
+  flagged ``isSphere`` emits ONE sphere record (centre = model . centroid, radius = |centroid - vertices[0]| .
+  scale / 1.7320508), any other mesh one ``Triangle(v1, v2, v3, matType, texIdx)`` per index triple;
+* the gather order of ``PbrtEngine::__genTrianglesFromScene`` (src/pbrt/pbrt_engine.cu:167-178): meshes are kept
+  in a ``std::map<std::string, MESH_PTR>`` (main.cpp:711-713), i.e. name-sorted; the mesh named "light" goes first;
+* the default scene of ``main()`` (main.cpp:408-500).
+
+The reference's default scene cannot be reproduced as its author ran it: it needs
+``models/teapot.obj`` and ``models/cube.obj`` through assimp, per-mesh pose files under ``.\\cache\\position`` and a
+binary camera snapshot, all git-ignored and absent.  ``default_scene()`` is therefore the documented restatement:
+everything the source specifies (light quad; four big spheres; the 11 x 11 field driven by the unseeded ``rand()``
+with the reference's draw order; half of the small bodies instanced as cubes; materials 10+U*20 / 30+U*20 / 7), a
+canonical +-1 twelve-triangle cube for ``cube.obj``, every cache-dependent scale = 1, the teapot omitted.  It also
+returns how many ``rand()`` calls the scene consumed, because the BVH builder continues the same sequence
+(``rt_build_bvh(ctx, rand_calls_before)``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import scenes
+from .engine import TRI_DTYPE, load_library
+
+F = np.float32
+
+
+class GlibcRand:
+    """glibc rand() in its default state, through the library's restatement (rt_test_glibc_rand)."""
+
+    def __init__(self, seed: int = 1, capacity: int = 4096):
+        lib = load_library()
+        self._buf = np.zeros(capacity, dtype=np.int32)
+        rc = lib.rt_test_glibc_rand(seed, capacity, self._buf.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        self.calls = 0
+
+    def rand(self) -> int:
+        v = int(self._buf[self.calls])
+        self.calls += 1
+        return v
+
+    def drand48(self) -> np.float32:
+        """The reference's wrapper (include/RT/triangle.h:12-15): rand() / (float)RAND_MAX."""
+        return F(F(self.rand()) / F(2147483647))
+
+
+def _translate(m: np.ndarray, v) -> np.ndarray:
+    """glm::translate(m, v): m[3] = m[0]*v.x + m[1]*v.y + m[2]*v.z + m[3]  (columns)."""
+    r = m.copy()
+    r[:, 3] = (m[:, 0] * F(v[0]) + m[:, 1] * F(v[1]) + m[:, 2] * F(v[2]) + m[:, 3]).astype(F)
+    return r
+
+
+def _scale(m: np.ndarray, s) -> np.ndarray:
+    r = m.copy()
+    for k in range(3):
+        r[:, k] = (m[:, k] * F(s)).astype(F)
+    return r
+
+
+def _apply(m: np.ndarray, p: np.ndarray) -> np.ndarray:
+    """vec3(m * vec4(p, 1)) for an (n, 3) array: glm sums column by column, x first."""
+    p = np.asarray(p, dtype=F).reshape(-1, 3)
+    out = np.zeros_like(p)
+    for r in range(3):
+        acc = (m[r, 0] * p[:, 0]).astype(F)
+        acc = (acc + (m[r, 1] * p[:, 1]).astype(F)).astype(F)
+        acc = (acc + (m[r, 2] * p[:, 2]).astype(F)).astype(F)
+        out[:, r] = (acc + m[r, 3]).astype(F)
+    return out
+
+
+class Mesh:
+    """GL-free restatement of the fields of ``Mesh`` that reach the kernel."""
+
+    def __init__(self, name: str, vertices, indices, mat_type: int = 0, tex_idx: int = -1):
+        self.name = name
+        self.vertices = np.asarray(vertices, dtype=F).reshape(-1, 3)
+        self.indices = np.asarray(indices, dtype=np.int64).reshape(-1)
+        self.mat_type = mat_type
+        self.tex_idx = tex_idx
+        self.translation = np.zeros(3, dtype=F)
+        self.rotation = np.eye(4, dtype=F)
+        self.scale = F(1.0)  # the reference's default is -1 until a pose file is loaded (mesh.h:85); see module doc
+        self.is_sphere = False
+        self.top = None  # FlyWeight support: setTopMesh (mesh.h:112-114)
+
+    # -- console commands (mesh.h:293-364)
+    def scale_command(self, amp: float):
+        self.scale = F(self.scale * F(amp))
+
+    def translate_command(self, x: float = 0.0, y: float = 0.0, z: float = 0.0):
+        self.translation = (self.translation + np.array([x, y, z], dtype=F)).astype(F)
+
+    def rotation_command(self, axis: int, degrees: float):
+        """rotation{X,Y,Z}Command: R = glm::rotate(I, d / 180 * PI, axis) * R.  cos/sin are numpy's float32 here (the
+        reference's are MSVC's cosf/sinf): last-bit agreement of a rotated pose is not claimed."""
+        a = F(F(degrees) / F(180.0) * F(3.14159265358979323846))
+        c, s = F(np.cos(a)), F(np.sin(a))
+        r = np.eye(4, dtype=F)
+        i, j = [(1, 2), (2, 0), (0, 1)][axis]
+        r[i, i], r[i, j], r[j, i], r[j, j] = c, -s, s, c
+        self.rotation = (r @ self.rotation).astype(F)
+
+    def reset_all(self):
+        self.rotation = np.eye(4, dtype=F)
+        self.translation = np.zeros(3, dtype=F)
+        self.scale = F(1.0)
+
+    def centroid(self) -> np.ndarray:
+        """resolvePosition (mesh.h:243-251): the vertex mean.  A mesh without vertices (a FlyWeight asked directly)
+        gives NaN, as the reference's 0/0 does."""
+        if self.vertices.shape[0] == 0:
+            return np.full(3, np.nan, dtype=F)
+        return (self.vertices.sum(axis=0, dtype=F) / F(self.vertices.shape[0])).astype(F)
+
+    def get_position(self) -> np.ndarray:
+        """getPosition (mesh.h:267-272): model . centroid."""
+        return _apply(self.get_model(), self.centroid()[None, :])[0]
+
+    def average_radius(self) -> np.float32:
+        """getAverageRadius (mesh.h:253-265): |centroid - vertices[0]| * scale / sqrt(3), scale from the top mesh."""
+        if self.vertices.shape[0] == 0:
+            return F(np.nan)
+        d = (self.centroid() - self.vertices[0]).astype(F)
+        dist = np.sqrt((d[0] * d[0] + d[1] * d[1] + d[2] * d[2]).astype(F)).astype(F)
+        return F(dist * self._who().scale / F(1.7320508075688772))
+
+    # -- what genTriangles reads, honouring the top mesh of a FlyWeight (mesh.h:104-144, 279-281)
+    def _who(self):
+        return self.top if self.top is not None else self
+
+    def get_mat_type(self) -> int:
+        return self._who().mat_type
+
+    def get_is_sphere(self) -> bool:
+        return self._who().is_sphere
+
+    def get_model(self) -> np.ndarray:
+        w = self._who()
+        m = np.eye(4, dtype=F)
+        m = _translate(m, w.translation)
+        m = (m @ w.rotation).astype(F)
+        return _scale(m, w.scale)
+
+    def gen_triangles(self) -> np.ndarray:
+        """Mesh::genTriangles, src/cxx/mesh.cpp:119-156."""
+        model = self.get_model()
+        if self.get_is_sphere():
+            centre = _apply(model, self.centroid()[None, :])
+            return scenes.make_spheres(centre, [self.average_radius()], self.get_mat_type())
+        tri = self.indices.reshape(-1, 3)
+        w = _apply(model, self.vertices)
+        return scenes.make_triangles(w[tri[:, 0]], w[tri[:, 1]], w[tri[:, 2]], self.get_mat_type(), self.tex_idx)
+
+
+class FlyWeight(Mesh):
+    """Re-emits a shared mesh under its own transform / material / sphere flag (mesh.h:591-622)."""
+
+    def __init__(self, name: str, orig: Mesh):
+        super().__init__(name, np.zeros((0, 3), dtype=F), [], 0)
+        self.orig = orig
+
+    def gen_triangles(self) -> np.ndarray:
+        self.orig.top = self
+        try:
+            return self.orig.gen_triangles()
+        finally:
+            self.orig.top = None
+
+
+def gather(meshes) -> np.ndarray:
+    """__genTrianglesFromScene (pbrt_engine.cu:167-178) over a std::map-ordered (name-sorted) collection."""
+    by_name = {}
+    for m in meshes:
+        by_name.setdefault(m.name, m)  # registerThisModel ignores a repeated name (mesh.h:232-239)
+    ordered = [by_name[k] for k in sorted(by_name, key=lambda s: s.encode())]
+    parts = [m.gen_triangles() for m in ordered if m.name == "light"]
+    parts += [m.gen_triangles() for m in ordered if m.name != "light"]
+    return np.concatenate(parts) if parts else np.zeros(0, dtype=TRI_DTYPE)
+
+
+def light_mesh() -> Mesh:
+    """make_a_cornell_light (include/RT/MeshFactory.h:423-429 -> 29-74): flipped quad at y = 10, material 3."""
+    v = [[4, 10, -4], [-4, 10, -4], [-4, 10, 4], [4, 10, 4]]
+    return Mesh("light", v, [3, 2, 1, 3, 1, 0], mat_type=3)
+
+
+def unit_cube_mesh(name: str = "cube") -> Mesh:
+    """Stand-in for models/cube.obj (absent): the canonical +-1 cube, 12 triangles."""
+    v = [[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]]
+    idx = [0, 2, 1, 0, 3, 2, 4, 5, 6, 4, 6, 7, 0, 1, 5, 0, 5, 4, 2, 3, 7, 2, 7, 6, 1, 2, 6, 1, 6, 5, 0, 4, 7, 0, 7, 3]
+    return Mesh(name, v, idx, mat_type=8)
+
+
+def default_meshes():
+    """main.cpp:408-500 restated (see the module docstring for what is assumed).  Returns (meshes, rand_calls):
+    the registered meshes in registration order and the number of rand() calls the scene setup consumed."""
+    rng = GlibcRand()
+    meshes = [light_mesh()]
+    cube = unit_cube_mesh("cube")  # mesh3: matType 8, flagged as a sphere (main.cpp:435-445)
+    cube.is_sphere = True
+    meshes.append(cube)
+    centers = [np.array(c, dtype=F) for c in ((0, -1000, 0), (0, 1, 0), (-4, 1, 0), (4, 1, 0))]
+    radii = [F(1000.0), F(1.0), F(1.0), F(1.0)]
+    mats = [0, 7, 4, 6]
+    flags = [True] * 4
+
+    def local_random():  # 2 * (drand48() - 0.5), double arithmetic on a float (main.cpp:449-451)
+        return F(2 * (float(rng.drand48()) - 0.5))
+
+    for a in range(-11, 11, 2):
+        for b in range(-11, 11, 2):
+            choose_mat = rng.drand48()
+            r = 0.2 + float(rng.drand48()) / 10  # `auto r` is a double (main.cpp:460)
+            cx = F(a + 0.2 * float(local_random()))  # x argument drawn first
+            cz = F(b + 0.2 * float(local_random()))
+            center = np.array([cx, F(r), cz], dtype=F)
+            d = (center - np.array([4, 0.2, 0], dtype=F)).astype(F)
+            length = np.sqrt((d[0] * d[0] + d[1] * d[1] + d[2] * d[2]).astype(F))
+            if float(length) > 0.9:
+                centers.append(center)
+                radii.append(F(r))
+                flags.append(not (float(rng.drand48()) < 0.5))
+                if float(choose_mat) < 0.3:
+                    mats.append(int(10 + float(rng.drand48()) * 20))
+                elif float(choose_mat) < 0.9:
+                    mats.append(int(30 + float(rng.drand48()) * 20))
+                else:
+                    mats.append(7)
+    for i, (c, r, m, flag) in enumerate(zip(centers, radii, mats, flags)):
+        fw = FlyWeight("c" + str(i), cube)
+        fw.mat_type = m
+        fw.translation = c.astype(F)  # setPositionFromVec3
+        fw.scale = F(r)
+        fw.is_sphere = bool(flag)
+        meshes.append(fw)
+    return meshes, rng.calls
+
+
+def default_scene():
+    """The default scene flattened as ``__genTrianglesFromScene`` does.  Returns (triangles, rand_calls): the
+    records in kernel order and the rand() calls consumed before the BVH build."""
+    meshes, calls = default_meshes()
+    return gather(meshes), calls
+
+
+def build_rand_calls(n: int) -> int:
+    """rand() calls one ``make_bvh_nodes`` build over n primitives makes (pbrt_engine.cu:335-368: one call per
+    invocation; an invocation over cnt > 2 primitives recurses into cnt/2 and cnt - cnt/2).  The reference never
+    reseeds, so the second ``render`` of a session continues where the first build stopped."""
+    memo = {}
+
+    def calls(cnt):
+        if cnt <= 2:
+            return 1
+        if cnt not in memo:
+            memo[cnt] = 1 + calls(cnt // 2) + calls(cnt - cnt // 2)
+        return memo[cnt]
+
+    return calls(n) if n > 0 else 0

@@ -39,6 +39,8 @@ class Oracle:
         lib.o_material_table.argtypes = [vp]
         lib.o_build_bvh.argtypes = [vp, C.c_int, vp]
         lib.o_build_bvh.restype = C.c_int
+        lib.o_build_bvh_after.argtypes = [vp, C.c_int, C.c_longlong, vp]
+        lib.o_build_bvh_after.restype = C.c_int
         lib.o_camera_update.argtypes = [vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
         lib.o_hit.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp]
         lib.o_hit_linear.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
@@ -70,12 +72,12 @@ class Oracle:
         self.lib.o_material_table(_p(out))
         return out
 
-    def build_bvh(self, tris):
+    def build_bvh(self, tris, rand_calls_before=0):
         from rt_amd.engine import NODE_DTYPE
 
         n = tris.shape[0]
         out = np.zeros(2 * n - 1, dtype=NODE_DTYPE)
-        m = self.lib.o_build_bvh(_p(tris), n, _p(out))
+        m = self.lib.o_build_bvh_after(_p(tris), n, C.c_longlong(rand_calls_before), _p(out))
         assert m == 2 * n - 1
         return out
 

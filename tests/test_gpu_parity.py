@@ -301,3 +301,84 @@ def test_full_size_1m_tris_lattice(oracle):
     # idempotence: a second launch gives the same frame
     assert eng.render().tobytes() == fb.tobytes()
     eng.close()
+
+
+@pytest.mark.skipif(not os.environ.get("RT_BIG_GRID"), reason="set RT_BIG_GRID=7072 for the 100M-triangle case (minutes, ~100 GB of host memory)")
+def test_big_scene_cfg5(oracle):
+    """BASELINE config 5 on one GPU: a G x G heightfield (G=7072 -> 100 026 370 triangles), 1080p, 16 spp, depth 8,
+    BVH replicated per GPU.  The frame is checked against the oracle on a sparse pixel lattice (the oracle traverses
+    the product's reference-tree nodes; its own serial builder would take tens of minutes at this size)."""
+    import time
+
+    G = int(os.environ["RT_BIG_GRID"])
+    t0 = time.time()
+    tris = scenes.heightfield(G)
+    t1 = time.time()
+    eng = rt_amd.PbrtEngine(1920, 1080, 16, device=0)
+    eng.setTriangles(tris)
+    eng.buildBvh()
+    t2 = time.time()
+    eng.setMaxDepth(8)
+    eng.setCamera(**scenes.BENCH_CAMERA)
+    fb = eng.render()
+    st = eng.last_stats
+    print(f"\nBIG: {tris.shape[0]} triangles, scene {t1 - t0:.1f}s, build+layout+upload {t2 - t1:.1f}s, wide nodes {st.wide_nodes}, "
+          f"stack {st.stack_entries}, render {st.kernel_ms:.1f} ms, {st.rays} rays, {st.rays / st.kernel_ms / 1e3:.0f} Mrays/s")
+    ids, ts = eng.tracePrimary()
+    print(f"BIG: primary {eng.last_stats.kernel_ms:.2f} ms = {1920 * 1080 / eng.last_stats.kernel_ms / 1e3:.0f} Mrays/s")
+    nodes = eng.getBvhNodes()
+    cam = scenes.BENCH_CAMERA
+    ocam = oracle.camera(cam["lookfrom"], cam["lookat"], 40.0, 1920 / 1080, 0.0, 10.0)
+    lat = (11, 5, 60, 60)
+    fb_o, _ = oracle.render(tris, nodes, oracle.material_table(), ocam, 1920, 1080, 16, 8, mode=1, threads=16, lattice=lat)
+    sub = (slice(lat[1], None, lat[3]), slice(lat[0], None, lat[2]))
+    assert fb[sub].tobytes() == fb_o[sub].tobytes()
+    ids_o, ts_o, _ = oracle.trace_primary(tris, nodes, ocam, 1920, 1080, mode=1, threads=16, lattice=(3, 3, 20, 20))
+    sub = (slice(3, None, 20), slice(3, None, 20))
+    assert (ids[sub] != ids_o[sub]).sum() == 0 and ts[sub].tobytes() == ts_o[sub].tobytes()
+    eng.close()
+
+
+def test_console_session_default_scene(oracle, tmp_path):
+    """the default scene through the headless console -- `render param`, `render`, a pose command, a
+    second `render` (whose build continues the unseeded rand() sequence), `render -cache` after a camera command --
+    each frame bit-exact against the oracle fed the same records, the same rand() position and the same camera."""
+    from rt_amd import console as rc
+    from rt_amd import scene_graph as sg
+
+    meshes, calls = sg.default_meshes()
+    eng = rt_amd.PbrtEngine(device=0)
+    eng.setMaxDepth(12)
+    con = rc.Console(eng, meshes, calls, out_path=str(tmp_path / "output.ppm"))
+    con.camera.position = np.array([13, 2, 3], dtype=np.float32)  # the book view the scene was laid out for
+    con.camera.front = np.array([-13, -2, -3], dtype=np.float32) / np.float32(13.490738)
+    con.execute("render param 96 54 4")
+    mats = oracle.material_table()
+
+    def check(k_before):
+        tris = con.last_triangles
+        nodes = oracle.build_bvh(tris, k_before)
+        assert nodes.tobytes() == eng.getBvhNodes().tobytes()
+        c = con.camera
+        ocam = oracle.camera(c.position, c.position + c.front, 40.0, 96 / 54, float(c.aperture), float(c.dist_to_focus))
+        fb_o, cnt = oracle.render(tris, nodes, mats, ocam, 96, 54, 4, 12, mode=0)
+        assert eng.last_stats.rays == cnt.rays
+        assert con.last_frame.tobytes() == fb_o.tobytes()
+
+    out = con.execute("render")
+    assert "Console Error" not in out and "Total num of Triangles: 689" in out
+    check(calls)
+    assert (tmp_path / "output.ppm").read_bytes().startswith(b"P3\n96 54\n255\n")
+    con.execute("m c1")
+    con.execute("my 0.5")
+    con.execute("s 1.25")
+    out = con.execute("render")
+    assert "Console Error" not in out
+    assert np.array_equal(con.last_triangles[3]["v0"], [0, 1.5, 0])
+    check(calls + sg.build_rand_calls(689))
+    con.execute("camera aperture 0.1")
+    con.execute("camera dist_to_focus")  # focus on c1
+    out = con.execute("render -cache")
+    assert "INFO: using scene generated." in out
+    check(calls + sg.build_rand_calls(689))
+    eng.close()

@@ -1,0 +1,239 @@
+"""Scene flattening and the headless console: host logic, no GPU.
+
+The reference has no tests and its default scene depends on absent files (scene_graph.py's docstring), so these
+check the restatement against what the reference's source fixes: the gather order, the sphere rule, the rand()
+position handed to the builder, the console's words.  Parity of the records themselves: unpinned.
+"""
+import numpy as np
+import pytest
+
+from rt_amd import console as rc
+from rt_amd import engine, scene_graph as sg
+
+
+def test_default_scene_shape_and_order():
+    tris, calls = sg.default_scene()
+    meshes, calls2 = sg.default_meshes()
+    assert calls == calls2
+    # light first (pbrt_engine.cu:167-178), then std::map order: "c0" < "c1" < "c10" < ... < "cube"
+    assert tris[0]["matType"] == 3 and tris[1]["matType"] == 3 and tris[0]["shapeType"] == 0
+    assert np.array_equal(tris[0]["v0"], [4, 10, 4])  # flipped quad: indices 3,2,1 (MeshFactory.h:64-67)
+    names = sorted((m.name for m in meshes), key=lambda s: s.encode())
+    assert names[0] == "c0" and names[1] == "c1" and names[2] == "c10" and names[-1] == "light" and names[-2] == "cube"
+    # c0: the ground sphere, radius = |(1,1,1)| * 1000 / 1.7320508 = 1000
+    assert tris[2]["shapeType"] == 1 and np.array_equal(tris[2]["v0"], [0, -1000, 0]) and tris[2]["v1"][0] == np.float32(1000)
+    assert tris[3]["shapeType"] == 1 and tris[3]["matType"] == 7  # c1: glass at (0, 1, 0)
+    # the last record is mesh3 itself ("cube"), flagged as a sphere, material 8
+    assert tris[-1]["shapeType"] == 1 and tris[-1]["matType"] == 8
+    n_sph = int((tris["shapeType"] == 1).sum())
+    n_tri = int((tris["shapeType"] == 0).sum())
+    assert (n_tri - 2) % 12 == 0  # every non-sphere body is the 12-triangle cube
+    assert n_sph + (n_tri - 2) // 12 == len(meshes) - 1
+    assert np.all(tris["texIdx"][tris["shapeType"] == 0] == -1)
+    # rand() budget: 4 draws per cell (mat, radius, x, z) + 1 (sphere flag) + 1 more unless the cell is glass
+    cells = 11 * 11
+    accepted = len(meshes) - 2 - 4
+    assert 4 * cells + accepted <= calls <= 4 * cells + 2 * accepted
+    mats = np.array([m.mat_type for m in meshes[6:]])
+    assert np.all(((mats >= 10) & (mats < 50)) | (mats == 7))
+
+
+def test_default_scene_is_deterministic():
+    a, ca = sg.default_scene()
+    b, cb = sg.default_scene()
+    assert a.tobytes() == b.tobytes() and ca == cb
+
+
+def test_flyweight_uses_the_top_mesh_pose_and_material():
+    cube = sg.unit_cube_mesh()
+    fw = sg.FlyWeight("f", cube)
+    fw.mat_type = 31
+    fw.translation = np.array([1, 2, 3], dtype=np.float32)
+    fw.scale = np.float32(0.5)
+    t = fw.gen_triangles()
+    assert t.shape[0] == 12 and np.all(t["matType"] == 31)
+    pts = np.concatenate([t["v0"], t["v1"], t["v2"]])
+    assert np.array_equal(pts.min(axis=0), [0.5, 1.5, 2.5]) and np.array_equal(pts.max(axis=0), [1.5, 2.5, 3.5])
+    assert cube.top is None  # resetTopMesh
+    assert np.all(cube.gen_triangles()["matType"] == 8)
+    fw.is_sphere = True
+    s = fw.gen_triangles()
+    assert s.shape[0] == 1 and s[0]["shapeType"] == 1 and np.array_equal(s[0]["v0"], [1, 2, 3])
+    assert abs(float(s[0]["v1"][0]) - 0.5) < 1e-6
+
+
+def test_transform_commands():
+    m = sg.unit_cube_mesh()
+    m.translate_command(x=1.5)
+    m.translate_command(y=-2)
+    m.scale_command(2)
+    assert np.array_equal(m.get_position(), [1.5, -2, 0])
+    assert abs(float(m.average_radius()) - 2.0) < 1e-6
+    m.rotation_command(1, 90)  # ry 90: +x -> -z
+    p = sg._apply(m.get_model(), np.array([[1, 0, 0]], dtype=np.float32))[0]
+    assert np.allclose(p, [1.5, -2, -2], atol=1e-5)
+    m.reset_all()
+    assert np.array_equal(m.get_model(), np.eye(4, dtype=np.float32))
+
+
+def test_build_rand_calls_matches_the_builder():
+    """The console's bookkeeping: building n primitives after k draws, then m primitives, equals building the m
+    primitives after k + calls(n) draws."""
+    for n in (1, 2, 3, 7, 100, 689):
+        assert sg.build_rand_calls(n) >= 1
+    a = sg.default_scene()[0]
+    # direct check against the glibc restatement: the axis of the root of a second build is draw k + calls(n)
+    rng = sg.GlibcRand(capacity=4096)
+    k = 711
+    seq = [rng.rand() for _ in range(k + sg.build_rand_calls(689) + 1)]
+    axis = int(3 * np.float32(np.float32(seq[-1]) / np.float32(2147483647)))
+    nodes = engine.host_build_bvh(a, k + sg.build_rand_calls(689))
+    root = nodes[-1]
+    left_leaves, stack = [], [int(root["left"])]
+    while stack:
+        nd = nodes[stack.pop()]
+        if nd["left"] == nd["right"]:
+            left_leaves.append(int(nd["left"]))
+        else:
+            stack += [int(nd["left"]), int(nd["right"])]
+    right = sorted(set(range(a.shape[0])) - set(left_leaves))
+
+    def key(i):  # padded box min along the axis, up to the pad (same for every primitive class)
+        t = a[i]
+        if t["shapeType"] == 1:
+            return float(t["v0"][min(axis, 2)] - t["v1"][0])
+        return float(min(t["v0"][min(axis, 2)], t["v1"][min(axis, 2)], t["v2"][min(axis, 2)]))
+
+    assert max(key(i) for i in left_leaves) <= min(key(i) for i in right) + 1e-3
+
+
+class FakeEngine:
+    """Records what the console asks of the engine (the GPU run of the same session is in test_gpu_parity)."""
+
+    def __init__(self):
+        self.nx, self.ny, self.ns, self.tx, self.ty = 640, 360, 10, 16, 16
+        self.nx_ny_changed = False
+        self.log = []
+
+        class S:
+            kernel_ms = 12.5
+
+        self.last_stats = S()
+
+    def setNx(self, v):
+        self.nx_ny_changed |= v != self.nx
+        self.nx = v
+
+    def setNy(self, v):
+        self.nx_ny_changed |= v != self.ny
+        self.ny = v
+
+    def setNs(self, v):
+        self.ns = v
+
+    def uponPixelNumChange(self):
+        self.log.append(("resize", self.nx, self.ny, self.ns))
+
+    def setTriangles(self, t):
+        self.log.append(("tris", t.shape[0]))
+
+    def buildBvh(self, k=0):
+        self.log.append(("build", k))
+
+    def setCamera(self, a, b, vfov, focus, aperture):
+        self.log.append(("cam", tuple(float(x) for x in a), tuple(float(x) for x in b), vfov, focus, aperture))
+
+    def render(self):
+        self.log.append(("render",))
+        return np.zeros((self.ny, self.nx, 3), dtype=np.float32)
+
+
+def _console(tmp_path):
+    meshes, calls = sg.default_meshes()
+    eng = FakeEngine()
+    return rc.Console(eng, meshes, calls, out_path=None, snapshot_path=str(tmp_path / "cam.json")), eng, calls
+
+
+def test_console_render_words_and_rand_bookkeeping(tmp_path):
+    con, eng, calls = _console(tmp_path)
+    out = con.execute("render")
+    assert out.splitlines() == [
+        "rendering a 640[width]x360[height] image with 10 samples per pixel in 16x16 blocks.",
+        "INFO: generate scene.",
+        f"Total num of Triangles: {con.last_triangles.shape[0]}",
+        "took 0.0125 seconds.",
+        "PbrtEngine: rendering finished.",
+    ]
+    n = con.last_triangles.shape[0]
+    assert ("build", calls) in eng.log
+    assert ("cam", (0.0, 0.0, 3.0), (0.0, 0.0, 2.0), 45.0, 10.0, 0.0) in eng.log
+    out = con.execute("render -cache")
+    assert "INFO: using scene generated." in out and eng.log.count(("tris", n)) == 1
+    con.execute("render")
+    assert ("build", calls + sg.build_rand_calls(n)) in eng.log  # the sequence is never reseeded
+    assert con.execute("render status") == "PbrtEngine: rendering finished.\n"
+
+
+def test_console_param_hd_and_camera(tmp_path):
+    con, eng, _ = _console(tmp_path)
+    con.execute("render param 320 200 4")
+    assert (eng.nx, eng.ny, eng.ns) == (320, 200, 4) and eng.log[-1] == ("resize", 320, 200, 4)
+    k = len(eng.log)
+    con.execute("render param 320 200 9")  # only ns changed: no reallocation (nXnYChanged)
+    assert eng.ns == 9 and len(eng.log) == k
+    con.execute("render hd")
+    assert (eng.nx, eng.ny, eng.ns) == (1280, 720, 100)
+    con.execute("camera posx")
+    con.execute("camera aperture 0.25")
+    con.execute("camera dist_to_focus 7.5")
+    assert con.execute("camera info") == "3 0 0\n-1 0 0\n"
+    con.execute("camera log")
+    con.execute("camera negz")
+    con.execute("camera save")
+    con.execute("camera restore")
+    assert con.execute("camera info") == "3 0 0\n-1 0 0\n"
+    con.execute("camera load")
+    assert con.execute("camera info") == "0 0 -3\n0 0 1\n"
+    con.execute("render -cache")
+    con.execute("camera posx")
+    con.execute("render")
+    assert eng.log[-2] == ("cam", (3.0, 0.0, 0.0), (2.0, 0.0, 0.0), 45.0, 7.5, 0.25)
+    assert "curr camera speed: 2.5" in con.execute("camera speed")
+
+
+def test_console_mesh_commands(tmp_path):
+    con, eng, _ = _console(tmp_path)
+    assert con.execute("mx 1") == ""  # no model selected: ignored (main.cpp:224-226)
+    assert con.execute("m nothing") == "ERROR: Model nothing not found.\n"
+    assert con.execute("m cube") == "setting model finished.\n"
+    con.execute("mx 1.5")
+    con.execute("my 2")
+    con.execute("s 3")
+    assert con.execute("radius") == "radius => 3\n"
+    out = con.execute("camera dist_to_focus")
+    d = float(np.sqrt(np.float32(1.5 * 1.5 + 2 * 2 + 3 * 3)))
+    assert out == "INFO: set camera distance_to_focus to %g\n" % d
+    con.execute("render")
+    last = con.last_triangles[-1]  # "cube" sorts last
+    assert np.array_equal(last["v0"], [1.5, 2, 0]) and abs(float(last["v1"][0]) - 3.0) < 1e-6
+    con.execute("reset")
+    con.execute("render")
+    assert np.array_equal(con.last_triangles[-1]["v0"], [0, 0, 0])
+    assert con.execute("s abc").startswith("Console Error:")  # std::stof throws, the loop survives
+    assert con.execute("m").startswith("Console Error:")
+    assert "Console Error" in con.execute("new xy")
+    assert con.loop and con.execute("q").startswith("bye") and not con.loop
+
+
+def test_console_line_is_cut_at_29_characters(tmp_path):
+    con, eng, _ = _console(tmp_path)
+    con.execute("render param 1280 720 100 extra")  # getline(input, 30): "render param 1280 720 100 ext"
+    assert (eng.nx, eng.ny, eng.ns) == (1280, 720, 100)
+
+
+def test_builder_continues_the_rand_sequence_like_the_oracle(oracle):
+    """rt_build_bvh(ctx, k) against the oracle's srand(1) + k discarded draws + make_bvh_nodes (real glibc rand(),
+    real std::sort), on the default scene at the two positions a console session reaches."""
+    tris, calls = sg.default_scene()
+    for k in (0, calls, calls + sg.build_rand_calls(tris.shape[0])):
+        assert engine.host_build_bvh(tris, k).tobytes() == oracle.build_bvh(tris, k).tobytes()
