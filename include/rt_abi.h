@@ -109,7 +109,8 @@ int rt_set_materials(rt_ctx *ctx, const rt_material *mats, int n);
 
 /* camera_update (pbrt_engine.cu:626-632) -> camera::update (include/RT/rt_camera.h:37-52).
  * vfov is accepted and, like the reference (:629), ignored: the field of view is 40 degrees
- * unless RT_OPT_HONOR_VFOV is set.  aspect = nx/ny of the last rt_resize. */
+ * unless RT_OPT_HONOR_VFOV is set.  aspect = nx/ny of the last rt_resize.  Non-finite parameters are refused
+ * (RT_E_ARG): the reference would trace NaN rays, whose result is outside the parity claim. */
 int rt_set_camera(rt_ctx *ctx, const float lookfrom[3], const float lookat[3], float vfov, float dist_to_focus,
                   float aperture);
 
@@ -122,16 +123,19 @@ enum {
     RT_OPT_SHARD_RANK = 5,  /* multi-GPU tile sharding: this context renders the 8x8 tiles with */
     RT_OPT_SHARD_WORLD = 6, /*   tile_index % world == rank; other pixels are written as 0 */
     RT_OPT_KERNEL = 7,      /* kernel variant, see DESIGN.md: 0 = one wave per tile, 1 = persistent waves
-                               with per-lane refill, 2 = 1 + speculative traversal (postponed leaves) */
+                               with per-lane refill, 2 = 1 + speculative traversal (postponed leaves),
+                               3 = 2 + two paths per lane (render only; primary / ray queries run as 2) */
     RT_OPT_REFILL_THRESHOLD = 8, /* kernel 1: refill when fewer than this many of 64 lanes still traverse */
     RT_OPT_WAVES_PER_CU = 9,     /* kernel 1: persistent waves launched per CU */
     RT_OPT_LDS_STACK = 10,       /* kernel 1: stack entries per lane kept in LDS (the rest spill to HBM) */
     RT_OPT_NODE_FORMAT = 11,     /* kernel 1/2: 0 = 128-byte float nodes, 1 = 64-byte quantized nodes (default) */
     RT_OPT_LEAF_BATCH = 12,      /* kernel 2: primitive tests run when this many lanes have a leaf pending */
     RT_OPT_OCCUPANCY = 13,       /* kernel 1/2, quantized nodes: waves per SIMD the registers are held to: 4, 6, 8 */
-    RT_OPT_TOPOLOGY = 14         /* device hierarchy: 0 = the reference's tree, wide-ified; 1 = a binned-SAH tree
+    RT_OPT_TOPOLOGY = 14,        /* device hierarchy: 0 = the reference's tree, wide-ified; 1 = a binned-SAH tree
                                     re-built over the same primitives (default).  Results are identical;
                                     rt_get_bvh_nodes always returns the reference's tree. */
+    RT_OPT_SHADE_BATCH = 15,     /* kernel 3: lanes with shading work queued that end a traversal phase */
+    RT_OPT_SWAP_BATCH = 16       /* kernel 3: lanes waiting to exchange their two paths that trigger the exchange */
 };
 int rt_set_option(rt_ctx *ctx, int option, int64_t value);
 int rt_get_option(rt_ctx *ctx, int option, int64_t *value);
@@ -169,6 +173,10 @@ int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *
 /* The tile-sharding rule alone (no GPU needed): owner[j*nx+i] = rank that renders pixel (i, j) when the frame
  * is split over `world` contexts (RT_OPT_SHARD_RANK / RT_OPT_SHARD_WORLD). */
 int rt_test_tile_owner(int nx, int ny, int world, int32_t *owner);
+
+/* Lane-occupancy counters of the last persistent-kernel launch (analysis builds only: `make STATS=1` builds
+ * librt_amd_stats.so; the shipped library returns RT_E_UNSUPPORTED).  Layout: rt_amd/csrc/kernels.h kStat*. */
+int rt_test_trav_stats(rt_ctx *ctx, uint64_t out[16]);
 
 #ifdef __cplusplus
 }

@@ -41,7 +41,14 @@ struct PersistLaunch {
     int speculative; // 1 = postpone leaves (speculative traversal)
     int leaf_batch;
     int occupancy; // 4, 6 or 8 waves per SIMD the kernel's registers are held to (quantized nodes only)
+    int dual;        // render only: 1 = k_dual (two paths per lane); implies speculative traversal
+    int shade_batch; // k_dual: lanes with shading work queued that end a traversal phase
+    int swap_batch;  // k_dual: lanes waiting to exchange their two paths that trigger the exchange
+    unsigned long long *stats; // kTravStats counters, zeroed by the caller; only written by a -DRT_TRAV_STATS build
 };
+// Lane-occupancy counters of the persistent kernel (analysis builds only, `make STATS=1`; tools/trav_stats.py)
+enum { kStatIters = 0, kStatNodeLanes, kStatStalledLanes, kStatIdleLanes, kStatLeafFires, kStatLeafLanes, kStatLeafPrims,
+       kStatRefills, kStatShadeLanes, kStatPrimaryLanes, kStatFetchLanes, kStatNodeIters, kStatRetiredLanes, kTravStats = 16 };
 hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &F, const PersistLaunch &L, float *fb,
                              int32_t *ids, float *ts, hipStream_t stream);
 hipError_t launch_render(const KernelScene &S, const KernelFrame &F, int stack_entries, float *fb, hipStream_t stream);

@@ -754,7 +754,14 @@ struct PersistArgs {
     int threshold;               // leave the traversal loop when fewer lanes than this are traversing
     int leaf_batch;              // SPEC: run the primitive tests when this many lanes have a leaf pending
     uint32_t total_lanes;
+    unsigned long long *stats;
 };
+
+#ifdef RT_TRAV_STATS
+#define RT_STAT(I, V) st[I] += (unsigned long long)(V)
+#else
+#define RT_STAT(I, V) ((void)0)
+#endif
 
 // MODE 0: render() (pbrt_engine.cu:569-595).  MODE 1: primary ray of sample 0 per pixel -> hit id, t.
 // SPEC 1: speculative traversal (Aila & Laine): a lane that reaches a leaf postpones it and keeps
@@ -788,9 +795,14 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
     Trav T;
     trav_begin(T, cur);
     uint32_t nr = 0;
+#ifdef RT_TRAV_STATS
+    unsigned long long st[kTravStats] = {0};
+#endif
 
     for (;;) {
         // ---------------- refill phase: lanes that are not traversing
+        RT_STAT(kStatRefills, 1);
+        RT_STAT(kStatShadeLanes, __popcll(__ballot(has_pixel && result_ready)));
         if (has_pixel && result_ready) {
             result_ready = false;
             Hit h;
@@ -830,6 +842,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
         {
             uint32_t slot = 0;
             const bool need = !has_pixel && !retired;
+            RT_STAT(kStatFetchLanes, __popcll(__ballot(need)));
             const bool got = fetch_slot<64u>(P.band_counters, n_tiles, home, q, need, slot);
             if (need) {
                 if (!got) {
@@ -851,6 +864,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                 }
             }
         }
+        RT_STAT(kStatPrimaryLanes, __popcll(__ballot(has_pixel && !tracing && need_primary)));
         if (has_pixel && !tracing) {
             if (need_primary) {
                 cur = primary_ray(F.cam, pi, pj, F.nx, F.ny, g);
@@ -869,6 +883,9 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
             const unsigned long long act = __ballot(tracing);
             if (act == 0ull) break;
             if ((int)__popcll(act) < P.threshold && __ballot(!tracing && !retired) != 0ull) break;
+            RT_STAT(kStatIters, 1);
+            RT_STAT(kStatIdleLanes, 64 - __popcll(act));
+            RT_STAT(kStatRetiredLanes, __popcll(__ballot(retired && !tracing)));
             if (SPEC == 0) {
                 if (tracing) {
                     if (!trav_step<FMT>(T, S, cur, K)) {
@@ -877,6 +894,14 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                     }
                 }
             } else {
+#ifdef RT_TRAV_STATS
+                {
+                    const int nl = __popcll(__ballot(tracing && !(T.cur & kLeafBit)));
+                    RT_STAT(kStatNodeLanes, nl);
+                    RT_STAT(kStatNodeIters, nl != 0);
+                    RT_STAT(kStatStalledLanes, __popcll(__ballot(tracing && T.cur != RT_REF_NONE && (T.cur & kLeafBit) && T.pend != RT_REF_NONE)));
+                }
+#endif
                 if (tracing && !(T.cur & kLeafBit)) node_step<FMT>(T, S, K);
                 // park a reached leaf in the pending slot and go on with the next stack entry
                 if (tracing && T.pend == RT_REF_NONE && T.cur != RT_REF_NONE && (T.cur & kLeafBit)) {
@@ -888,6 +913,15 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                 if (leaf_mask != 0ull) {
                     const unsigned long long node_mask = __ballot(tracing && !(T.cur & kLeafBit));
                     if (node_mask == 0ull || (int)__popcll(leaf_mask) >= P.leaf_batch) {
+                        RT_STAT(kStatLeafFires, 1);
+                        RT_STAT(kStatLeafLanes, __popcll(leaf_mask));
+#ifdef RT_TRAV_STATS
+                        {
+                            uint32_t np = want_leaf ? ((T.pend >> 28) & 7u) + 1u : 0u;
+                            for (int o = 32; o > 0; o >>= 1) np += __shfl_xor(np, o);
+                            RT_STAT(kStatLeafPrims, np);
+                        }
+#endif
                         if (want_leaf) {
                             leaf_test(T, S, cur, T.pend);
                             T.pend = RT_REF_NONE;
@@ -902,6 +936,234 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
         }
     }
     add_rays(F.ray_counter, nr);
+#ifdef RT_TRAV_STATS
+    if (lane == 0 && P.stats)
+        for (int i = 0; i < kTravStats; i++)
+            if (st[i]) atomicAdd(&P.stats[i], st[i]);
+#endif
+}
+
+// ------------------------------------------------------------------ two paths per lane
+// k_persistent's counters (tools/trav_stats.py) show where its lanes go on diffuse paths: rays are short (16 node
+// steps), so a lane finishes often; with one path per lane it then sits idle until enough lanes have finished
+// to make the (expensive) shading step worth running -- 24 of 64 lanes idle in the average traversal iteration,
+// and shading itself runs with 23.  k_dual gives every lane a second path, parked in registers:
+//   slot T: the path being traversed (its ray, the traversal state, the LDS stack);
+//   slot W: a path that waits -- READY (has a ray to trace), DONE (traversal result waiting to be shaded) or EMPTY.
+// When T finishes and W is READY the two exchange (v_swap_b32: 21 instructions) and the lane keeps traversing;
+// shading always works on slot W, and runs when `shade_batch` lanes have work for it.  Paths are independent
+// (one pixel, one RNG stream each), so the order in which a lane interleaves its two paths cannot change a result.
+#define RT_W_EMPTY 0
+#define RT_W_READY 1
+#define RT_W_DONE 2
+#define RT_T_EMPTY 0
+#define RT_T_TRACING 1
+#define RT_T_DONE 2
+
+struct PathRegs { // what shading needs besides the ray and the hit: 15 registers
+    Rng g;
+    V3 col, thr;
+    uint32_t pij; // pixel: j << 16 | i
+    int k, bounce;
+};
+
+__device__ __forceinline__ void vswap(float &a, float &b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void vswap(uint32_t &a, uint32_t &b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void vswap(int &a, int &b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void vswap(V3 &a, V3 &b) {
+    vswap(a.x, b.x);
+    vswap(a.y, b.y);
+    vswap(a.z, b.z);
+}
+__device__ __forceinline__ void vswap(PathRegs &a, PathRegs &b) {
+    vswap(a.g.v0, b.g.v0);
+    vswap(a.g.v1, b.g.v1);
+    vswap(a.g.v2, b.g.v2);
+    vswap(a.g.v3, b.g.v3);
+    vswap(a.g.v4, b.g.v4);
+    vswap(a.g.d, b.g.d);
+    vswap(a.col, b.col);
+    vswap(a.thr, b.thr);
+    vswap(a.pij, b.pij);
+    vswap(a.k, b.k);
+    vswap(a.bounce, b.bounce);
+}
+
+struct DualArgs {
+    int shade_batch; // leave the traversal phase when this many lanes have shading / fetch work in slot W
+    int swap_batch;  // exchange T and W when this many lanes wait for it (or nothing else is traversing)
+};
+
+template <int FMT, int OCC>
+__global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, PersistArgs P, DualArgs D, float *fb) {
+    const uint32_t lane = threadIdx.x;
+    StackRef K;
+    K.lds = s_stack + lane;
+    K.spill = P.spill + (size_t)blockIdx.x * 64u + lane;
+    K.lds_entries = P.lds_entries;
+    K.spill_stride = P.total_lanes;
+    const uint32_t home = xcc_id();
+    const uint32_t n_tiles = (uint32_t)F.n_local_tiles;
+    SlotQueue q;
+    q.next = q.end = q.bands_tried = 0u;
+
+    PathRegs pt, pw;
+    pt.g.v0 = pt.g.v1 = pt.g.v2 = pt.g.v3 = pt.g.v4 = pt.g.d = 0;
+    pt.col = pt.thr = mk(0, 0, 0);
+    pt.pij = 0;
+    pt.k = pt.bounce = 0;
+    pw = pt;
+    Ray cur, wr;
+    cur.o = wr.o = mk(0, 0, 0);
+    cur.d = wr.d = mk(0, 0, 1);
+    float wt = 0.0f;
+    int wrank = RT_NO_HIT;
+    int t_status = RT_T_EMPTY, w_status = RT_W_EMPTY;
+    bool retired = false;
+    Trav T;
+    trav_begin(T, cur);
+    T.cur = RT_REF_NONE;
+    uint32_t nr = 0;
+#ifdef RT_TRAV_STATS
+    unsigned long long st[kTravStats] = {0};
+#endif
+
+    for (;;) {
+        // ---------------- shading phase: slot W
+        RT_STAT(kStatRefills, 1);
+        RT_STAT(kStatShadeLanes, __popcll(__ballot(w_status == RT_W_DONE)));
+        bool need_primary = false;
+        if (w_status == RT_W_DONE) {
+            Hit h;
+            h.t = wt;
+            h.rank = wrank;
+            bool clamp;
+            const bool go_on = shade_bounce(S, h, wr, pw.thr, pw.g, clamp);
+            pw.bounce++;
+            w_status = RT_W_READY;
+            if (!go_on || pw.bounce >= F.max_depth) {
+                if (clamp) clip_color(pw.thr);
+                pw.col = vadd(pw.col, pw.thr);
+                pw.k++;
+                if (pw.k == F.ns) {
+                    const float kk = (float)(1.0 / (double)(float)F.ns);
+                    V3 c = mk(pw.col.x * kk, pw.col.y * kk, pw.col.z * kk);
+                    clip_color(c);
+                    const size_t pixel_index = (size_t)(pw.pij >> 16) * (size_t)F.nx + (size_t)(pw.pij & 0xFFFFu);
+                    fb[3 * pixel_index + 0] = c.x;
+                    fb[3 * pixel_index + 1] = c.y;
+                    fb[3 * pixel_index + 2] = c.z;
+                    w_status = RT_W_EMPTY;
+                } else {
+                    need_primary = true;
+                }
+            }
+        }
+        {
+            uint32_t slot = 0;
+            const bool need = w_status == RT_W_EMPTY && !retired;
+            RT_STAT(kStatFetchLanes, __popcll(__ballot(need)));
+            const bool got = fetch_slot<64u>(P.band_counters, n_tiles, home, q, need, slot);
+            if (need) {
+                if (!got) {
+                    retired = true;
+                } else {
+                    const uint32_t local = slot >> 6, within = slot & 63u;
+                    const uint32_t gt = local * (uint32_t)F.shard_world + (uint32_t)F.shard_rank;
+                    const int tx = (int)(gt % (uint32_t)F.tiles_x), ty = (int)(gt / (uint32_t)F.tiles_x);
+                    const int pi = tx * 8 + (int)(within & 7u), pj = ty * 8 + (int)(within >> 3);
+                    if (pi < F.nx && pj < F.ny) { // ragged edge tiles: the slot is simply dropped
+                        pw.pij = ((uint32_t)pj << 16) | (uint32_t)pi;
+                        rng_init(pw.g, (uint64_t)(1995 + pj * F.nx + pi));
+                        pw.col = mk(0, 0, 0);
+                        pw.k = 0;
+                        need_primary = true;
+                    }
+                }
+            }
+        }
+        RT_STAT(kStatPrimaryLanes, __popcll(__ballot(need_primary)));
+        if (need_primary) {
+            wr = primary_ray(F.cam, (int)(pw.pij & 0xFFFFu), (int)(pw.pij >> 16), F.nx, F.ny, pw.g);
+            pw.thr = mk(1.0f, 1.0f, 1.0f);
+            pw.bounce = 0;
+            w_status = RT_W_READY;
+        }
+        if (__ballot(!(retired && t_status == RT_T_EMPTY && w_status == RT_W_EMPTY)) == 0ull) break;
+
+        // ---------------- traversal phase: slot T
+        for (;;) {
+            unsigned long long act = __ballot(t_status == RT_T_TRACING);
+            {
+                // T has nothing to traverse and W has a ray, or T holds a result and W is free to take it
+                const bool want = t_status != RT_T_TRACING &&
+                                  (w_status == RT_W_READY || (t_status == RT_T_DONE && w_status == RT_W_EMPTY));
+                const unsigned long long sw = __ballot(want);
+                if (sw != 0ull && ((int)__popcll(sw) >= D.swap_batch || act == 0ull)) {
+                    if (want) {
+                        vswap(pt, pw);
+                        vswap(cur.o, wr.o);
+                        vswap(cur.d, wr.d);
+                        wt = T.best_t;
+                        wrank = T.best_rank;
+                        const int new_w = t_status == RT_T_DONE ? RT_W_DONE : RT_W_EMPTY;
+                        if (w_status == RT_W_READY) {
+                            trav_begin(T, cur);
+                            t_status = RT_T_TRACING;
+                            nr++;
+                        } else {
+                            t_status = RT_T_EMPTY;
+                        }
+                        w_status = new_w;
+                    }
+                    act = __ballot(t_status == RT_T_TRACING);
+                }
+            }
+            if (act == 0ull) break;
+            {
+                const unsigned long long work = __ballot(w_status == RT_W_DONE || (w_status == RT_W_EMPTY && !retired));
+                if ((int)__popcll(work) >= D.shade_batch) break;
+                if ((int)__popcll(act) < P.threshold && work != 0ull) break;
+            }
+            RT_STAT(kStatIters, 1);
+            RT_STAT(kStatIdleLanes, 64 - __popcll(act));
+            RT_STAT(kStatRetiredLanes, __popcll(__ballot(retired && t_status == RT_T_EMPTY && w_status == RT_W_EMPTY)));
+            const bool tracing = t_status == RT_T_TRACING;
+#ifdef RT_TRAV_STATS
+            {
+                const int nl = __popcll(__ballot(tracing && !(T.cur & kLeafBit)));
+                RT_STAT(kStatNodeLanes, nl);
+                RT_STAT(kStatNodeIters, nl != 0);
+                RT_STAT(kStatStalledLanes, __popcll(__ballot(tracing && T.cur != RT_REF_NONE && (T.cur & kLeafBit) && T.pend != RT_REF_NONE)));
+            }
+#endif
+            if (tracing && !(T.cur & kLeafBit)) node_step<FMT>(T, S, K);
+            if (tracing && T.pend == RT_REF_NONE && T.cur != RT_REF_NONE && (T.cur & kLeafBit)) {
+                T.pend = T.cur;
+                T.cur = pop_or_none(K, T.sp);
+            }
+            const bool want_leaf = tracing && T.pend != RT_REF_NONE;
+            const unsigned long long leaf_mask = __ballot(want_leaf);
+            if (leaf_mask != 0ull) {
+                const unsigned long long node_mask = __ballot(tracing && !(T.cur & kLeafBit));
+                if (node_mask == 0ull || (int)__popcll(leaf_mask) >= P.leaf_batch) {
+                    RT_STAT(kStatLeafFires, 1);
+                    RT_STAT(kStatLeafLanes, __popcll(leaf_mask));
+                    if (want_leaf) {
+                        leaf_test(T, S, cur, T.pend);
+                        T.pend = RT_REF_NONE;
+                    }
+                }
+            }
+            if (tracing && T.cur == RT_REF_NONE && T.pend == RT_REF_NONE) t_status = RT_T_DONE;
+        }
+    }
+    add_rays(F.ray_counter, nr);
+#ifdef RT_TRAV_STATS
+    if (lane == 0 && P.stats)
+        for (int i = 0; i < kTravStats; i++)
+            if (st[i]) atomicAdd(&P.stats[i], st[i]);
+#endif
 }
 
 // ------------------------------------------------------------------ launchers (host)
@@ -949,7 +1211,21 @@ hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &
     P.threshold = L.threshold;
     P.leaf_batch = L.leaf_batch;
     P.total_lanes = (uint32_t)L.grid_waves * 64u;
+    P.stats = L.stats;
     const dim3 grid(L.grid_waves), block(64);
+    if (mode == 0 && L.dual) {
+        DualArgs D;
+        D.shade_batch = L.shade_batch;
+        D.swap_batch = L.swap_batch;
+        if (F.nx > 65535 || F.ny > 65535) return hipErrorInvalidValue; // pixel coordinates are packed 16:16
+        if (L.node_format == 0)
+            hipLaunchKernelGGL((k_dual<0, 4>), grid, block, lds, stream, S, F, P, D, fb);
+        else if (L.occupancy >= 6)
+            hipLaunchKernelGGL((k_dual<1, 6>), grid, block, lds, stream, S, F, P, D, fb);
+        else
+            hipLaunchKernelGGL((k_dual<1, 4>), grid, block, lds, stream, S, F, P, D, fb);
+        return hipGetLastError();
+    }
 #define RT_LAUNCH(M, Fm, Sp, Oc)                                                                                       \
     hipLaunchKernelGGL((k_persistent<M, Fm, Sp, Oc>), grid, block, lds, stream, S, F, P, fb, ids, ts)
 #define RT_LAUNCH_OCC(M, Sp)                                                                                           \

@@ -30,6 +30,7 @@ struct rt_ctx {
     // NX/NY/NS, include/RT/pbrt_engine.h:24-26 ; ITER_NUM, pbrt_engine.cu:458
     int nx = 640, ny = 360, ns = 10, max_depth = 50;
     int honor_vfov = 0, leaf_size = 2, box_mode = 0, shard_rank = 0, shard_world = 1, kernel_variant = 2;
+    int shade_batch = 32, swap_batch = 8;
     int refill_threshold = 32, waves_per_cu = 24, lds_stack = 16, node_format = 1, leaf_batch = 16, occupancy = 6, topology = 1;
     int n_cus = 256;
     unsigned int *d_bands = nullptr;
@@ -57,6 +58,9 @@ struct rt_ctx {
 };
 
 namespace {
+
+// eight band counters (64 bytes with padding), then the kTravStats analysis counters
+constexpr size_t kBandBytes = 64 + sizeof(unsigned long long) * kTravStats;
 
 int fail(rt_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg;
@@ -241,7 +245,10 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L) {
     L.lds_entries = c->lds_stack < c->wide.stack_entries ? c->lds_stack : c->wide.stack_entries;
     L.threshold = c->refill_threshold;
     L.node_format = c->node_format;
-    L.speculative = c->kernel_variant == 2 ? 1 : 0;
+    L.speculative = c->kernel_variant >= 2 ? 1 : 0;
+    L.dual = c->kernel_variant == 3 ? 1 : 0;
+    L.shade_batch = c->shade_batch;
+    L.swap_batch = c->swap_batch;
     L.leaf_batch = c->leaf_batch;
     L.occupancy = c->occupancy;
     int spill_entries = c->wide.stack_entries - L.lds_entries;
@@ -255,7 +262,8 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L) {
     }
     L.spill = c->d_spill;
     L.band_counters = c->d_bands;
-    HIPCHK(c, hipMemsetAsync(c->d_bands, 0, sizeof(unsigned int) * 8, c->stream));
+    L.stats = reinterpret_cast<unsigned long long *>(c->d_bands + 16);
+    HIPCHK(c, hipMemsetAsync(c->d_bands, 0, kBandBytes, c->stream));
     return RT_OK;
 }
 
@@ -325,7 +333,7 @@ int rt_create(rt_ctx **out, int device_id) {
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e);
     if ((e = hipMalloc((void **)&c->d_counter, sizeof(unsigned long long))) != hipSuccess) return bail(e);
     if ((e = hipMalloc((void **)&c->d_mats, sizeof(DevMat) * RT_MAT_NUM)) != hipSuccess) return bail(e);
-    if ((e = hipMalloc((void **)&c->d_bands, sizeof(unsigned int) * 8)) != hipSuccess) return bail(e);
+    if ((e = hipMalloc((void **)&c->d_bands, kBandBytes)) != hipSuccess) return bail(e);
     {
         hipDeviceProp_t prop;
         if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail(e);
@@ -429,6 +437,11 @@ int rt_set_materials(rt_ctx *c, const rt_material *mats, int n) {
 int rt_set_camera(rt_ctx *c, const float lookfrom[3], const float lookat[3], float vfov, float dist_to_focus,
                   float aperture) {
     if (!c || !lookfrom || !lookat) return RT_E_ARG;
+    // A non-finite camera makes every ray NaN; the reference then reports NaN-t "hits" that depend on which boxes it
+    // happened to visit, which no other hierarchy reproduces: refuse instead of diverging silently.
+    bool finite = std::isfinite(vfov) && std::isfinite(dist_to_focus) && std::isfinite(aperture);
+    for (int k = 0; k < 3; k++) finite = finite && std::isfinite(lookfrom[k]) && std::isfinite(lookat[k]);
+    if (!finite) return fail(c, RT_E_ARG, "camera parameters must be finite");
     for (int k = 0; k < 3; k++) {
         c->lookfrom[k] = lookfrom[k];
         c->lookat[k] = lookat[k];
@@ -470,7 +483,7 @@ int rt_set_option(rt_ctx *c, int option, int64_t value) {
         if (c->shard_rank >= c->shard_world) c->shard_rank = 0;
         return RT_OK;
     case RT_OPT_KERNEL:
-        if (value < 0 || value > 2) return fail(c, RT_E_ARG, "kernel variant 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(c, RT_E_ARG, "kernel variant 0..3");
         c->kernel_variant = (int)value;
         return RT_OK;
     case RT_OPT_REFILL_THRESHOLD:
@@ -496,6 +509,14 @@ int rt_set_option(rt_ctx *c, int option, int64_t value) {
     case RT_OPT_OCCUPANCY:
         if (value != 4 && value != 6 && value != 8) return fail(c, RT_E_ARG, "occupancy 4, 6 or 8");
         c->occupancy = (int)value;
+        return RT_OK;
+    case RT_OPT_SHADE_BATCH:
+        if (value < 1 || value > 64) return fail(c, RT_E_ARG, "shade batch 1..64");
+        c->shade_batch = (int)value;
+        return RT_OK;
+    case RT_OPT_SWAP_BATCH:
+        if (value < 1 || value > 64) return fail(c, RT_E_ARG, "swap batch 1..64");
+        c->swap_batch = (int)value;
         return RT_OK;
     case RT_OPT_TOPOLOGY:
         if (value != 0 && value != 1) return fail(c, RT_E_ARG, "topology 0 or 1");
@@ -524,6 +545,8 @@ int rt_get_option(rt_ctx *c, int option, int64_t *value) {
     case RT_OPT_LEAF_BATCH: *value = c->leaf_batch; return RT_OK;
     case RT_OPT_OCCUPANCY: *value = c->occupancy; return RT_OK;
     case RT_OPT_TOPOLOGY: *value = c->topology; return RT_OK;
+    case RT_OPT_SHADE_BATCH: *value = c->shade_batch; return RT_OK;
+    case RT_OPT_SWAP_BATCH: *value = c->swap_batch; return RT_OK;
     default: return fail(c, RT_E_ARG, "unknown option");
     }
 }
@@ -725,6 +748,17 @@ int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *
     if (quant_nodes) std::memcpy(quant_nodes, w.qnodes.data(), w.qnodes.size() * sizeof(QuantNode));
     if (prims) std::memcpy(prims, w.prims.data(), w.prims.size() * sizeof(DevPrim));
     return RT_OK;
+}
+
+int rt_test_trav_stats(rt_ctx *c, uint64_t out[16]) {
+    if (!c || !out) return RT_E_ARG;
+#ifdef RT_TRAV_STATS
+    if (hipSetDevice(c->device) != hipSuccess) return RT_E_HIP;
+    HIPCHK(c, hipMemcpy(out, c->d_bands + 16, sizeof(uint64_t) * kTravStats, hipMemcpyDeviceToHost));
+    return RT_OK;
+#else
+    return fail(c, RT_E_UNSUPPORTED, "built without RT_TRAV_STATS (make STATS=1 builds librt_amd_stats.so)");
+#endif
 }
 
 int rt_test_tile_owner(int nx, int ny, int world, int32_t *owner) {

@@ -14,7 +14,8 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+# RT_AMD_LIB: load another build of the same library (the analysis build librt_amd_stats.so, tools/trav_stats.py)
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")
 
 # reference Triangle, include/RT/triangle.h:345-354 (148 bytes)
 TRI_DTYPE = np.dtype(
@@ -37,6 +38,7 @@ assert MAT_DTYPE.itemsize == 20
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_LIGHT = 0, 1, 2, 3
 OPT_MAX_DEPTH, OPT_HONOR_VFOV, OPT_LEAF_SIZE, OPT_BOX_MODE, OPT_SHARD_RANK, OPT_SHARD_WORLD, OPT_KERNEL = 1, 2, 3, 4, 5, 6, 7
 OPT_REFILL_THRESHOLD, OPT_WAVES_PER_CU, OPT_LDS_STACK, OPT_NODE_FORMAT, OPT_LEAF_BATCH, OPT_OCCUPANCY, OPT_TOPOLOGY = 8, 9, 10, 11, 12, 13, 14
+OPT_SHADE_BATCH, OPT_SWAP_BATCH = 15, 16
 
 
 class RtStats(C.Structure):
@@ -63,6 +65,7 @@ ABI_SYMBOLS = [
     "rt_set_bvh_nodes", "rt_get_bvh_nodes", "rt_default_materials", "rt_set_materials", "rt_set_camera",
     "rt_set_option", "rt_get_option", "rt_render", "rt_render_device", "rt_trace_primary", "rt_trace_rays",
     "rt_write_ppm", "rt_test_glibc_rand", "rt_test_introsort", "rt_test_build_bvh", "rt_test_wide_layout", "rt_test_tile_owner",
+    "rt_test_trav_stats",
 ]
 
 

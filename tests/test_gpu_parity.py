@@ -188,6 +188,31 @@ def test_kernel_variants_bit_exact(oracle, kernel, fmt, thr, batch, lds, topo):
         eng.close()
 
 
+@pytest.mark.parametrize("fmt,occ,thr,batch,shade,swap,lds,topo", [(1, 4, 32, 16, 32, 8, 16, 1), (1, 6, 48, 8, 64, 1, 3, 1),
+                                                                    (0, 4, 1, 64, 1, 64, 16, 0), (1, 4, 64, 1, 16, 32, 64, 0),
+                                                                    (1, 4, 16, 24, 48, 4, 2, 1)])
+def test_two_paths_per_lane_kernel_bit_exact(oracle, fmt, occ, thr, batch, shade, swap, lds, topo):
+    """Kernel 3 (two paths per lane, exchanged when the traced one finishes; shading batched on the parked one):
+    whatever the batch sizes -- including the degenerate ones that exchange or shade one lane at a time, or only
+    when nothing else can run -- the frame is the oracle's, bit for bit; ragged frame edges and a frame smaller than
+    the launch (most lanes never get a pixel) included."""
+    opts = {engine.OPT_KERNEL: 3, engine.OPT_NODE_FORMAT: fmt, engine.OPT_OCCUPANCY: occ, engine.OPT_REFILL_THRESHOLD: thr,
+            engine.OPT_LEAF_BATCH: batch, engine.OPT_SHADE_BATCH: shade, engine.OPT_SWAP_BATCH: swap, engine.OPT_LDS_STACK: lds,
+            engine.OPT_WAVES_PER_CU: 2, engine.OPT_TOPOLOGY: topo}
+    for tris, cam, nx, ny, ns, depth in ((scenes.heightfield(50), scenes.BENCH_CAMERA, 150, 85, 4, 8),
+                                         (scenes.spheres_scene(), scenes.DEFAULT_CAMERA, 90, 50, 3, 30),
+                                         (scenes.spheres_scene(3), scenes.DEFAULT_CAMERA, 13, 9, 2, 50)):
+        eng = _engine(tris, nx, ny, ns, depth, cam, opts)
+        fb = eng.render()
+        rays = eng.last_stats.rays
+        nodes = eng.getBvhNodes()
+        ocam = oracle.camera(cam["lookfrom"], cam["lookat"], 40.0, nx / ny, cam["aperture"], cam["dist_to_focus"])
+        fb_o, cnt = oracle.render(tris, nodes, oracle.material_table(), ocam, nx, ny, ns, depth, mode=1)
+        assert rays == cnt.rays
+        assert fb.tobytes() == fb_o.tobytes()
+        eng.close()
+
+
 def test_injected_nodes_and_cached_render(oracle):
     """rt_set_bvh_nodes with the oracle's node array ("render -cache" reuses the built scene)."""
     tris = scenes.heightfield(20)
@@ -377,8 +402,12 @@ def test_console_session_default_scene(oracle, tmp_path):
     assert np.array_equal(con.last_triangles[3]["v0"], [0, 1.5, 0])
     check(calls + sg.build_rand_calls(689))
     con.execute("camera aperture 0.1")
-    con.execute("camera dist_to_focus")  # focus on c1
+    # focus on the selected FlyWeight: it owns no vertices, getPosition() is 0/0 in the reference too; refused here
+    assert "distance_to_focus to nan" in con.execute("camera dist_to_focus")
+    assert "camera parameters must be finite" in con.execute("render -cache")
+    con.execute("m cube")
+    assert "distance_to_focus to 13.49" in con.execute("camera dist_to_focus")
     out = con.execute("render -cache")
-    assert "INFO: using scene generated." in out
+    assert "INFO: using scene generated." in out and "Console Error" not in out
     check(calls + sg.build_rand_calls(689))
     eng.close()

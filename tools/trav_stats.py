@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Lane occupancy of the persistent kernel on the bench workload, from the analysis build:
+    make -C rt_amd/csrc STATS=1 && RT_AMD_LIB=rt_amd/librt_amd_stats.so python tools/trav_stats.py [run_frame-like args]
+Prints, per launch, how many of the 64 lanes did useful work in each phase of the loop."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+import rt_amd  # noqa: E402
+from rt_amd import engine as E  # noqa: E402
+from rt_amd import scenes  # noqa: E402
+
+NAMES = ["iters", "node_lanes", "stalled_lanes", "idle_lanes", "leaf_fires", "leaf_lanes", "leaf_prims", "refills",
+         "shade_lanes", "primary_lanes", "fetch_lanes", "node_iters", "retired_lanes"]
+
+
+def stats(eng):
+    out = np.zeros(16, dtype=np.uint64)
+    eng._check(eng._lib.rt_test_trav_stats(eng._h, out.ctypes.data_as(C.c_void_p)), "rt_test_trav_stats")
+    d = {n: int(out[i]) for i, n in enumerate(NAMES)}
+    it = max(d["iters"], 1)
+    d["node_lanes_per_iter"] = d["node_lanes"] / it
+    d["node_lanes_per_node_iter"] = d["node_lanes"] / max(d["node_iters"], 1)
+    d["stalled_per_iter"] = d["stalled_lanes"] / it
+    d["idle_per_iter"] = d["idle_lanes"] / it
+    d["retired_per_iter"] = d["retired_lanes"] / it
+    d["leaf_lanes_per_fire"] = d["leaf_lanes"] / max(d["leaf_fires"], 1)
+    d["leaf_prims_per_lane"] = d["leaf_prims"] / max(d["leaf_lanes"], 1)
+    d["iters_per_leaf_fire"] = it / max(d["leaf_fires"], 1)
+    d["shade_lanes_per_refill"] = d["shade_lanes"] / max(d["refills"], 1)
+    d["iters_per_refill"] = it / max(d["refills"], 1)
+    return d
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--grid", type=int, default=708)
+    ap.add_argument("--nx", type=int, default=1920)
+    ap.add_argument("--ny", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=16)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--threshold", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--leaf", type=int, default=None)
+    ap.add_argument("--kernel", type=int, default=None)
+    ap.add_argument("--shade", type=int, default=None)
+    ap.add_argument("--swap", type=int, default=None)
+    ap.add_argument("--occ", type=int, default=None)
+    ap.add_argument("--waves", type=int, default=None)
+    args = ap.parse_args()
+    eng = rt_amd.PbrtEngine(args.nx, args.ny, args.spp, device=0)
+    if args.threshold is not None:
+        eng.setOption(E.OPT_REFILL_THRESHOLD, args.threshold)
+    if args.batch is not None:
+        eng.setOption(E.OPT_LEAF_BATCH, args.batch)
+    if args.leaf is not None:
+        eng.setOption(E.OPT_LEAF_SIZE, args.leaf)
+    for opt, v in ((E.OPT_KERNEL, args.kernel), (E.OPT_SHADE_BATCH, args.shade), (E.OPT_SWAP_BATCH, args.swap),
+                   (E.OPT_OCCUPANCY, args.occ), (E.OPT_WAVES_PER_CU, args.waves)):
+        if v is not None:
+            eng.setOption(opt, v)
+    eng.setTriangles(scenes.heightfield(args.grid))
+    eng.buildBvh()
+    eng.setMaxDepth(args.depth)
+    eng.setCamera(**scenes.BENCH_CAMERA)
+    eng.render()
+    d = stats(eng)
+    d.update(kind="render", kernel_ms=eng.last_stats.kernel_ms, rays=int(eng.last_stats.rays))
+    d["node_steps_per_ray"] = d["node_lanes"] / d["rays"]
+    d["leaf_tests_per_ray"] = d["leaf_lanes"] / d["rays"]
+    print(json.dumps(d), flush=True)
+    eng.tracePrimary()
+    d = stats(eng)
+    d.update(kind="primary", kernel_ms=eng.last_stats.kernel_ms, rays=int(eng.last_stats.rays))
+    d["node_steps_per_ray"] = d["node_lanes"] / d["rays"]
+    d["leaf_tests_per_ray"] = d["leaf_lanes"] / d["rays"]
+    print(json.dumps(d), flush=True)
+
+
+if __name__ == "__main__":
+    main()
