@@ -44,11 +44,18 @@ struct PersistLaunch {
     int dual;        // render only: 1 = k_dual (two paths per lane); implies speculative traversal
     int shade_batch; // k_dual: lanes with shading work queued that end a traversal phase
     int swap_batch;  // k_dual: lanes waiting to exchange their two paths that trigger the exchange
+    // rounds (render only): the frame is walked `rounds` times, pixels hand their state on between rounds; see
+    // "Rounds" at k_persistent
+    int rounds;            // 1 = off; at most 63 and at most ns
+    uint32_t *round_state; // kRingWords words per slot (n_local_tiles * 64 slots)
+    uint32_t *round_flag;  // one word per slot; zeroed once at allocation
+    uint32_t frame_id;     // never 0, below 2^26; flags of earlier launches compare unequal: no clearing per frame
     unsigned long long *stats; // kTravStats counters, zeroed by the caller; only written by a -DRT_TRAV_STATS build
 };
+enum { kRingWords = 12 };
 // Lane-occupancy counters of the persistent kernel (analysis builds only, `make STATS=1`; tools/trav_stats.py)
 enum { kStatIters = 0, kStatNodeLanes, kStatStalledLanes, kStatIdleLanes, kStatLeafFires, kStatLeafLanes, kStatLeafPrims,
-       kStatRefills, kStatShadeLanes, kStatPrimaryLanes, kStatFetchLanes, kStatNodeIters, kStatRetiredLanes, kTravStats = 16 };
+       kStatRefills, kStatShadeLanes, kStatPrimaryLanes, kStatFetchLanes, kStatNodeIters, kStatRetiredLanes, kStatWaitLanes, kStatSpinPolls, kTravStats = 16 };
 hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &F, const PersistLaunch &L, float *fb,
                              int32_t *ids, float *ts, hipStream_t stream);
 hipError_t launch_render(const KernelScene &S, const KernelFrame &F, int stack_entries, float *fb, hipStream_t stream);

@@ -709,12 +709,14 @@ __device__ __forceinline__ uint32_t band_begin(uint32_t n_tiles, uint32_t b) { r
 // costs about a microsecond: per-ray fetches would dominate short primary rays); `need` lanes take
 // consecutive slots from it.  When the band is empty the wave steals from the next one; after all eight
 // are empty the remaining `need` lanes get false.  slot = local tile index * 64 + lane-in-tile.
+// With rounds > 1 (render only) every band is walked `rounds` times, round-major: a band's counter runs over
+// rounds * band_slots, and the slot's round comes back in `round` (see "Rounds" at k_persistent).
 struct SlotQueue { // wave-uniform
-    uint32_t next, end, bands_tried;
+    uint32_t next, end, bands_tried, round;
 };
 template <uint32_t CHUNK>
 __device__ __forceinline__ bool fetch_slot(unsigned int *band_counters, uint32_t n_tiles, uint32_t home, SlotQueue &q,
-                                           bool need, uint32_t &slot) {
+                                           bool need, uint32_t &slot, uint32_t rounds, uint32_t &round) {
     const uint32_t lane = lane_id();
     for (int guard = 0; guard < 64; guard++) {
         const unsigned long long mask = __ballot(need);
@@ -728,11 +730,15 @@ __device__ __forceinline__ bool fetch_slot(unsigned int *band_counters, uint32_t
             uint32_t base = 0;
             if (lane == 0u) base = atomicAdd(&band_counters[b], CHUNK);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (base >= band_slots) {
+            if (base >= band_slots * rounds) { // also true for an empty band (band_slots == 0)
                 q.bands_tried++;
             } else {
-                q.next = begin * 64u + base;
-                q.end = begin * 64u + (base + CHUNK < band_slots ? base + CHUNK : band_slots);
+                // band_slots is a multiple of 64 = CHUNK: a run never straddles two rounds
+                const uint32_t r = rounds > 1u ? base / band_slots : 0u;
+                const uint32_t off = base - r * band_slots;
+                q.round = r;
+                q.next = begin * 64u + off;
+                q.end = begin * 64u + (off + CHUNK < band_slots ? off + CHUNK : band_slots);
             }
             continue;
         }
@@ -740,6 +746,7 @@ __device__ __forceinline__ bool fetch_slot(unsigned int *band_counters, uint32_t
         const uint32_t before = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         if (need && before < avail) {
             slot = q.next + before;
+            round = q.round;
             need = false;
         }
         q.next += cnt < avail ? cnt : avail;
@@ -755,7 +762,25 @@ struct PersistArgs {
     int leaf_batch;              // SPEC: run the primitive tests when this many lanes have a leaf pending
     uint32_t total_lanes;
     unsigned long long *stats;
+    int rounds;            // 1 = off
+    uint32_t *round_state; // kRingWords words per slot
+    uint32_t *round_flag;  // one word per slot: frame_id * 64 + the round whose start state the slot holds
+    uint32_t frame_id;
 };
+
+// Rounds.  A pixel is the unit of work the reference allows (one RNG stream per pixel, its samples in sequence),
+// and one pixel of the bench frame is ~140 rays: when the pixel queue runs dry every lane is somewhere inside its
+// last pixel, waves thin out lane by lane, and 15 % of all lane-iterations of the frame belong to lanes that have
+// nothing left to do (tools/trav_stats.py).  The pixels started last set the length of that tail, so no pixel may
+// start late: the frame is walked in R rounds.  In round r a lane takes a slot exactly as before (same bands, same
+// chunks, same XCD affinity), runs samples [r*ns/R, (r+1)*ns/R) of that pixel, writes the pixel's state (RNG, sum,
+// sample count: 11 words) to the slot's record and goes on to the next slot; the lane that takes the slot in round
+// r+1 -- any lane of any wave -- picks the state up.  All pixels advance together and the frame ends on units of
+// ns/R samples.  A record has one writer and one reader per round, in turn, so one record per slot is enough; its
+// flag names the round it holds (frame_id * 64 + round).  A lane whose record is not there yet keeps the slot and
+// polls; the writer never waits for anything, so this cannot deadlock.  Who runs which samples cannot change a value.
+// Hand-off between lanes of different CUs / XCDs: state and flag are written and read with system-scope
+// (volatile -> sc0 sc1) accesses, the state drained (vmcnt(0)) before the flag is written.
 
 #ifdef RT_TRAV_STATS
 #define RT_STAT(I, V) st[I] += (unsigned long long)(V)
@@ -780,11 +805,11 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
     const uint32_t home = xcc_id();
     const uint32_t n_tiles = (uint32_t)F.n_local_tiles;
     SlotQueue q;
-    q.next = q.end = q.bands_tried = 0u;
+    q.next = q.end = q.bands_tried = q.round = 0u;
 
     // per-lane path state
     bool has_pixel = false, retired = false, tracing = false, result_ready = false, need_primary = false;
-    int pi = 0, pj = 0, pixel_index = 0;
+    uint32_t pij = 0; // pixel in hand: j << 16 | i (rt_resize keeps both below 65536)
     Rng g;
     g.v0 = g.v1 = g.v2 = g.v3 = g.v4 = g.d = 0;
     V3 col = mk(0, 0, 0), thr = mk(1, 1, 1);
@@ -795,6 +820,12 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
     Trav T;
     trav_begin(T, cur);
     uint32_t nr = 0;
+    bool waiting = false;   // slot taken in a round > 0 whose record has not been published yet
+    uint32_t slot_round = 0; // slot of the pixel in hand | round << 26 (slots < 2^26, rounds < 64)
+    int yield_k = 0;        // sample count at which it is handed on (ns: never)
+    const bool ring_on = MODE == 0 && P.rounds > 1;
+    const uint32_t rounds = ring_on ? (uint32_t)P.rounds : 1u;
+    int since_poll = 0;
 #ifdef RT_TRAV_STATS
     unsigned long long st[kTravStats] = {0};
 #endif
@@ -802,12 +833,15 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
     for (;;) {
         // ---------------- refill phase: lanes that are not traversing
         RT_STAT(kStatRefills, 1);
+        since_poll = 0;
+        bool want_push = false;
         RT_STAT(kStatShadeLanes, __popcll(__ballot(has_pixel && result_ready)));
         if (has_pixel && result_ready) {
             result_ready = false;
             Hit h;
             h.t = T.best_t;
             h.rank = T.best_rank;
+            const size_t pixel_index = (size_t)(pij >> 16) * (size_t)F.nx + (size_t)(pij & 0xFFFFu);
             if (MODE == 1) {
                 if (h.rank != RT_NO_HIT) {
                     ids[pixel_index] = __float_as_int(S.prims[3 * (size_t)h.rank + 2].z);
@@ -829,21 +863,41 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                         float kk = (float)(1.0 / (double)(float)F.ns);
                         col = mk(col.x * kk, col.y * kk, col.z * kk);
                         clip_color(col);
-                        fb[3 * (size_t)pixel_index + 0] = col.x;
-                        fb[3 * (size_t)pixel_index + 1] = col.y;
-                        fb[3 * (size_t)pixel_index + 2] = col.z;
+                        fb[3 * pixel_index + 0] = col.x;
+                        fb[3 * pixel_index + 1] = col.y;
+                        fb[3 * pixel_index + 2] = col.z;
                         has_pixel = false;
+                    } else if (ring_on && k == yield_k) {
+                        want_push = true;
                     } else {
                         need_primary = true;
                     }
                 }
             }
         }
+        if (ring_on && want_push) { // end of this round's share: publish state, drain, flag
+            const uint32_t my_slot = slot_round & 0x3FFFFFFu;
+            volatile uint32_t *sp = P.round_state + (size_t)my_slot * kRingWords;
+            sp[1] = g.v0;
+            sp[2] = g.v1;
+            sp[3] = g.v2;
+            sp[4] = g.v3;
+            sp[5] = g.v4;
+            sp[6] = g.d;
+            sp[7] = __float_as_uint(col.x);
+            sp[8] = __float_as_uint(col.y);
+            sp[9] = __float_as_uint(col.z);
+            sp[10] = (uint32_t)k;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            *(volatile uint32_t *)(P.round_flag + my_slot) = P.frame_id * 64u + (slot_round >> 26) + 1u; // next round's tag
+            has_pixel = false;
+        }
         {
             uint32_t slot = 0;
-            const bool need = !has_pixel && !retired;
+            const bool need = !has_pixel && !retired && !waiting;
             RT_STAT(kStatFetchLanes, __popcll(__ballot(need)));
-            const bool got = fetch_slot<64u>(P.band_counters, n_tiles, home, q, need, slot);
+            uint32_t round = 0;
+            const bool got = fetch_slot<64u>(P.band_counters, n_tiles, home, q, need, slot, rounds, round);
             if (need) {
                 if (!got) {
                     retired = true;
@@ -851,23 +905,46 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                     const uint32_t local = slot >> 6, within = slot & 63u;
                     const uint32_t gt = local * (uint32_t)F.shard_world + (uint32_t)F.shard_rank;
                     const int tx = (int)(gt % (uint32_t)F.tiles_x), ty = (int)(gt / (uint32_t)F.tiles_x);
-                    pi = tx * 8 + (int)(within & 7u);
-                    pj = ty * 8 + (int)(within >> 3);
-                    if (pi < F.nx && pj < F.ny) { // ragged edge tiles: the slot is simply dropped
-                        pixel_index = pj * F.nx + pi;
-                        rng_init(g, (uint64_t)(1995 + pixel_index));
-                        col = mk(0, 0, 0);
-                        k = 0;
-                        has_pixel = true;
-                        need_primary = true;
+                    const int pi = tx * 8 + (int)(within & 7u), pj = ty * 8 + (int)(within >> 3);
+                    if (pi < F.nx && pj < F.ny) { // ragged edge tiles: the slot is simply dropped, in every round
+                        pij = ((uint32_t)pj << 16) | (uint32_t)pi;
+                        slot_round = slot | (round << 26);
+                        // this round runs samples up to (round + 1) * ns / rounds; the last round ends at ns
+                        yield_k = round + 1u < rounds ? (int)(((uint64_t)(round + 1u) * (uint64_t)F.ns) / rounds) : F.ns;
+                        if (round == 0u) {
+                            rng_init(g, (uint64_t)(1995 + pj * F.nx + pi));
+                            col = mk(0, 0, 0);
+                            k = 0;
+                            has_pixel = true;
+                            need_primary = true;
+                        } else {
+                            waiting = true;
+                        }
                     }
+                }
+            }
+            if (ring_on && waiting) { // has the previous round's lane published it yet?
+                const uint32_t my_slot = slot_round & 0x3FFFFFFu;
+                if (*(volatile uint32_t *)(P.round_flag + my_slot) == P.frame_id * 64u + (slot_round >> 26)) {
+                    volatile uint32_t *sp = P.round_state + (size_t)my_slot * kRingWords;
+                    g.v0 = sp[1];
+                    g.v1 = sp[2];
+                    g.v2 = sp[3];
+                    g.v3 = sp[4];
+                    g.v4 = sp[5];
+                    g.d = sp[6];
+                    col = mk(__uint_as_float(sp[7]), __uint_as_float(sp[8]), __uint_as_float(sp[9]));
+                    k = (int)sp[10];
+                    has_pixel = true;
+                    need_primary = true;
+                    waiting = false;
                 }
             }
         }
         RT_STAT(kStatPrimaryLanes, __popcll(__ballot(has_pixel && !tracing && need_primary)));
         if (has_pixel && !tracing) {
             if (need_primary) {
-                cur = primary_ray(F.cam, pi, pj, F.nx, F.ny, g);
+                cur = primary_ray(F.cam, (int)(pij & 0xFFFFu), (int)(pij >> 16), F.nx, F.ny, g);
                 thr = mk(1.0f, 1.0f, 1.0f);
                 bounce = 0;
                 need_primary = false;
@@ -877,15 +954,24 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
             nr++;
         }
         if (__ballot(!retired) == 0ull) break;
+        if (ring_on && __ballot(tracing) == 0ull) {
+            // every live lane waits for a ring item: nothing to do but poll.  Sleep between polls (127 x 64 clocks,
+            // ~3.5 us) so that the waiting wave leaves the SIMD's issue slots to the waves that still produce.
+            RT_STAT(kStatSpinPolls, 1);
+            __builtin_amdgcn_s_sleep(127);
+        }
 
         // ---------------- traversal phase
         for (;;) {
             const unsigned long long act = __ballot(tracing);
             if (act == 0ull) break;
-            if ((int)__popcll(act) < P.threshold && __ballot(!tracing && !retired) != 0ull) break;
+            // lanes the refill phase could do something for (a lane that waits for a ring item is not one)
+            if ((int)__popcll(act) < P.threshold && __ballot(!tracing && !retired && !waiting) != 0ull) break;
+            if (ring_on && ++since_poll > 8 && __ballot(waiting) != 0ull) break; // poll now and then
             RT_STAT(kStatIters, 1);
             RT_STAT(kStatIdleLanes, 64 - __popcll(act));
             RT_STAT(kStatRetiredLanes, __popcll(__ballot(retired && !tracing)));
+            RT_STAT(kStatWaitLanes, __popcll(__ballot(waiting)));
             if (SPEC == 0) {
                 if (tracing) {
                     if (!trav_step<FMT>(T, S, cur, K)) {
@@ -1005,7 +1091,7 @@ __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, 
     const uint32_t home = xcc_id();
     const uint32_t n_tiles = (uint32_t)F.n_local_tiles;
     SlotQueue q;
-    q.next = q.end = q.bands_tried = 0u;
+    q.next = q.end = q.bands_tried = q.round = 0u;
 
     PathRegs pt, pw;
     pt.g.v0 = pt.g.v1 = pt.g.v2 = pt.g.v3 = pt.g.v4 = pt.g.d = 0;
@@ -1063,7 +1149,8 @@ __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, 
             uint32_t slot = 0;
             const bool need = w_status == RT_W_EMPTY && !retired;
             RT_STAT(kStatFetchLanes, __popcll(__ballot(need)));
-            const bool got = fetch_slot<64u>(P.band_counters, n_tiles, home, q, need, slot);
+            uint32_t round = 0;
+            const bool got = fetch_slot<64u>(P.band_counters, n_tiles, home, q, need, slot, 1u, round);
             if (need) {
                 if (!got) {
                     retired = true;
@@ -1201,7 +1288,7 @@ hipError_t launch_render(const KernelScene &S, const KernelFrame &F, int stack_e
 hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &F, const PersistLaunch &L, float *fb,
                              int32_t *ids, float *ts, hipStream_t stream) {
     if (F.n_local_tiles <= 0) return hipSuccess;
-    if (L.lds_entries < 1 || L.grid_waves < 1) return hipErrorInvalidValue;
+    if (L.lds_entries < 1 || L.grid_waves < 1 || F.nx > 65535 || F.ny > 65535) return hipErrorInvalidValue; // pij packing
     size_t lds = (size_t)L.lds_entries * 64 * sizeof(uint32_t);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     PersistArgs P;
@@ -1212,6 +1299,13 @@ hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &
     P.leaf_batch = L.leaf_batch;
     P.total_lanes = (uint32_t)L.grid_waves * 64u;
     P.stats = L.stats;
+    P.rounds = mode == 0 && L.rounds > 1 ? L.rounds : 1;
+    P.round_state = L.round_state;
+    P.round_flag = L.round_flag;
+    P.frame_id = L.frame_id;
+    if (P.rounds > 1 && (!P.round_state || !P.round_flag || P.frame_id == 0u || P.rounds > 63 || P.rounds > F.ns ||
+                         (uint64_t)F.n_local_tiles * 64u >= (1ull << 26)))
+        return hipErrorInvalidValue;
     const dim3 grid(L.grid_waves), block(64);
     if (mode == 0 && L.dual) {
         DualArgs D;

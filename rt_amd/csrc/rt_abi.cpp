@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -30,7 +31,10 @@ struct rt_ctx {
     // NX/NY/NS, include/RT/pbrt_engine.h:24-26 ; ITER_NUM, pbrt_engine.cu:458
     int nx = 640, ny = 360, ns = 10, max_depth = 50;
     int honor_vfov = 0, leaf_size = 2, box_mode = 0, shard_rank = 0, shard_world = 1, kernel_variant = 2;
-    int shade_batch = 32, swap_batch = 8;
+    int shade_batch = 32, swap_batch = 8, tail_split = 8;
+    uint32_t *d_ring_state = nullptr, *d_ring_flag = nullptr;
+    size_t ring_items = 0;
+    uint32_t frame_id = 0;
     int refill_threshold = 32, waves_per_cu = 24, lds_stack = 16, node_format = 1, leaf_batch = 16, occupancy = 6, topology = 1;
     int n_cus = 256;
     unsigned int *d_bands = nullptr;
@@ -240,7 +244,7 @@ void fill_stats(rt_ctx *c, rt_stats *st, uint64_t rays, float ms, double total_m
 }
 
 // kernel variant 1: zero the band counters, size the spill area, fill the launch record
-int prepare_persistent(rt_ctx *c, PersistLaunch &L) {
+int prepare_persistent(rt_ctx *c, PersistLaunch &L, bool render) {
     L.grid_waves = c->n_cus * c->waves_per_cu;
     L.lds_entries = c->lds_stack < c->wide.stack_entries ? c->lds_stack : c->wide.stack_entries;
     L.threshold = c->refill_threshold;
@@ -262,6 +266,33 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L) {
     }
     L.spill = c->d_spill;
     L.band_counters = c->d_bands;
+    L.rounds = 1;
+    L.round_state = L.round_flag = nullptr;
+    L.frame_id = 0;
+    const int rounds = std::min(std::min(c->tail_split, c->ns), 63);
+    const long tiles = (long)((c->nx + 7) / 8) * ((c->ny + 7) / 8);
+    const size_t slots = (size_t)((tiles - c->shard_rank + c->shard_world - 1) / c->shard_world) * 64;
+    if (render && rounds > 1 && c->kernel_variant != 3 && slots > 0 && slots < ((size_t)1 << 26)) { // slot | round << 26
+        if (slots > c->ring_items) {
+            if (c->d_ring_state) (void)hipFree(c->d_ring_state);
+            if (c->d_ring_flag) (void)hipFree(c->d_ring_flag);
+            c->d_ring_state = c->d_ring_flag = nullptr;
+            c->ring_items = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_ring_state, slots * kRingWords * sizeof(uint32_t)));
+            HIPCHK(c, hipMalloc((void **)&c->d_ring_flag, slots * sizeof(uint32_t)));
+            HIPCHK(c, hipMemsetAsync(c->d_ring_flag, 0, slots * sizeof(uint32_t), c->stream));
+            c->ring_items = slots;
+            c->frame_id = 0;
+        }
+        if (++c->frame_id >= (1u << 26)) { // the tag is frame_id * 64 + round: start over before it wraps
+            HIPCHK(c, hipMemsetAsync(c->d_ring_flag, 0, c->ring_items * sizeof(uint32_t), c->stream));
+            c->frame_id = 1;
+        }
+        L.rounds = rounds;
+        L.round_state = c->d_ring_state;
+        L.round_flag = c->d_ring_flag;
+        L.frame_id = c->frame_id;
+    }
     L.stats = reinterpret_cast<unsigned long long *>(c->d_bands + 16);
     HIPCHK(c, hipMemsetAsync(c->d_bands, 0, kBandBytes, c->stream));
     return RT_OK;
@@ -352,6 +383,8 @@ int rt_destroy(rt_ctx *c) {
     if (c->d_mats) (void)hipFree(c->d_mats);
     if (c->d_counter) (void)hipFree(c->d_counter);
     if (c->d_bands) (void)hipFree(c->d_bands);
+    if (c->d_ring_state) (void)hipFree(c->d_ring_state);
+    if (c->d_ring_flag) (void)hipFree(c->d_ring_flag);
     if (c->d_spill) (void)hipFree(c->d_spill);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -366,6 +399,7 @@ int rt_resize(rt_ctx *c, int nx, int ny, int ns) {
     if (!c) return RT_E_ARG;
     if (nx <= 0 || ny <= 0 || ns <= 0) return fail(c, RT_E_ARG, "nx, ny, ns must be positive");
     if ((long)nx * ny > (1L << 30)) return fail(c, RT_E_LIMIT, "frame too large (pixel index must fit int32)");
+    if (nx > 65535 || ny > 65535) return fail(c, RT_E_LIMIT, "frame too large (at most 65535 pixels per side)");
     HIPCHK(c, hipSetDevice(c->device));
     c->nx = nx;
     c->ny = ny;
@@ -518,6 +552,10 @@ int rt_set_option(rt_ctx *c, int option, int64_t value) {
         if (value < 1 || value > 64) return fail(c, RT_E_ARG, "swap batch 1..64");
         c->swap_batch = (int)value;
         return RT_OK;
+    case RT_OPT_TAIL_SPLIT:
+        if (value < 1 || value > 63) return fail(c, RT_E_ARG, "rounds 1..63");
+        c->tail_split = (int)value;
+        return RT_OK;
     case RT_OPT_TOPOLOGY:
         if (value != 0 && value != 1) return fail(c, RT_E_ARG, "topology 0 or 1");
         if (c->topology != (int)value) c->scene_on_device = false;
@@ -547,6 +585,7 @@ int rt_get_option(rt_ctx *c, int option, int64_t *value) {
     case RT_OPT_TOPOLOGY: *value = c->topology; return RT_OK;
     case RT_OPT_SHADE_BATCH: *value = c->shade_batch; return RT_OK;
     case RT_OPT_SWAP_BATCH: *value = c->swap_batch; return RT_OK;
+    case RT_OPT_TAIL_SPLIT: *value = c->tail_split; return RT_OK;
     default: return fail(c, RT_E_ARG, "unknown option");
     }
 }
@@ -559,7 +598,7 @@ static int render_into(rt_ctx *c, float *d_fb, rt_stats *st, double t0) {
         HIPCHK(c, hipMemsetAsync(d_fb, 0, (size_t)c->nx * c->ny * 3 * sizeof(float), c->stream));
     PersistLaunch L;
     if (c->kernel_variant >= 1) {
-        int rc = prepare_persistent(c, L);
+        int rc = prepare_persistent(c, L, true);
         if (rc) return rc;
     }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -626,7 +665,7 @@ int rt_trace_primary(rt_ctx *c, int32_t *tri_id_host, float *t_host, rt_stats *s
     fill_frame(c, F);
     PersistLaunch L;
     if (c->kernel_variant >= 1) {
-        int rc2 = prepare_persistent(c, L);
+        int rc2 = prepare_persistent(c, L, false);
         if (rc2) {
             cleanup();
             return rc2;

@@ -38,7 +38,7 @@ assert MAT_DTYPE.itemsize == 20
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_LIGHT = 0, 1, 2, 3
 OPT_MAX_DEPTH, OPT_HONOR_VFOV, OPT_LEAF_SIZE, OPT_BOX_MODE, OPT_SHARD_RANK, OPT_SHARD_WORLD, OPT_KERNEL = 1, 2, 3, 4, 5, 6, 7
 OPT_REFILL_THRESHOLD, OPT_WAVES_PER_CU, OPT_LDS_STACK, OPT_NODE_FORMAT, OPT_LEAF_BATCH, OPT_OCCUPANCY, OPT_TOPOLOGY = 8, 9, 10, 11, 12, 13, 14
-OPT_SHADE_BATCH, OPT_SWAP_BATCH = 15, 16
+OPT_SHADE_BATCH, OPT_SWAP_BATCH, OPT_TAIL_SPLIT = 15, 16, 17
 
 
 class RtStats(C.Structure):

@@ -213,6 +213,32 @@ def test_two_paths_per_lane_kernel_bit_exact(oracle, fmt, occ, thr, batch, shade
         eng.close()
 
 
+@pytest.mark.parametrize("kernel,tail,ns,waves,world", [(2, 1, 16, 24, 1), (2, 2, 16, 2, 1), (2, 8, 17, 1, 1), (2, 63, 64, 3, 1), (1, 3, 5, 24, 1),
+                                                        (2, 8, 4, 2, 1), (2, 8, 3, 2, 1), (2, 8, 1, 2, 1), (2, 5, 21, 2, 3)])
+def test_tail_split_does_not_change_the_image(oracle, kernel, tail, ns, waves, world):
+    """RT_OPT_TAIL_SPLIT: the frame is walked in rounds and pixels hand their state (RNG, sum, sample count) to
+    whichever lane takes their slot next round.  Whatever the number of rounds (more rounds than samples included),
+    few waves (a lane waits for records its own wave has to write) or many (most lanes never see a pixel), sharded
+    or not: the oracle's image, bit for bit, twice in a row (a record's flag names frame and round; nothing is
+    cleared between frames)."""
+    tris, cam, nx, ny, depth = scenes.heightfield(40), scenes.BENCH_CAMERA, 93, 61, 6
+    opts = {engine.OPT_KERNEL: kernel, engine.OPT_TAIL_SPLIT: tail, engine.OPT_WAVES_PER_CU: waves}
+    eng = _engine(tris, nx, ny, ns, depth, cam, opts)
+    nodes = eng.getBvhNodes()
+    ocam = oracle.camera(cam["lookfrom"], cam["lookat"], 40.0, nx / ny, cam["aperture"], cam["dist_to_focus"])
+    fb_o, cnt = oracle.render(tris, nodes, oracle.material_table(), ocam, nx, ny, ns, depth, mode=1)
+    for _ in range(2):
+        total = np.zeros_like(fb_o)
+        rays = 0
+        for r in range(world):
+            eng.setShard(r, world)
+            total += eng.render()
+            rays += eng.last_stats.rays
+        assert rays == cnt.rays
+        assert total.tobytes() == fb_o.tobytes()
+    eng.close()
+
+
 def test_injected_nodes_and_cached_render(oracle):
     """rt_set_bvh_nodes with the oracle's node array ("render -cache" reuses the built scene)."""
     tris = scenes.heightfield(20)

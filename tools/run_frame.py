@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--topo", type=ints, default=[1])
     ap.add_argument("--shade", type=ints, default=[32])
     ap.add_argument("--swap", type=ints, default=[8])
+    ap.add_argument("--tail", type=ints, default=[2])
     args = ap.parse_args()
     tris = scenes.heightfield(args.grid)
     eng = rt_amd.PbrtEngine(args.nx, args.ny, args.spp, device=0)
@@ -45,7 +46,7 @@ def main():
     eng.setMaxDepth(args.depth)
     eng.setCamera(**scenes.BENCH_CAMERA)
     nodes = None
-    for leaf, bm, kv, th, wv, ld, fm, lb, oc, tp, sb, wb in itertools.product(args.leaf, args.box_mode, args.kernel, args.threshold, args.waves, args.lds, args.fmt, args.batch, args.occ, args.topo, args.shade, args.swap):
+    for leaf, bm, kv, th, wv, ld, fm, lb, oc, tp, sb, wb, ts in itertools.product(args.leaf, args.box_mode, args.kernel, args.threshold, args.waves, args.lds, args.fmt, args.batch, args.occ, args.topo, args.shade, args.swap, args.tail):
         eng.setOption(E.OPT_LEAF_SIZE, leaf)
         eng.setOption(E.OPT_BOX_MODE, bm)
         eng.setOption(E.OPT_KERNEL, kv)
@@ -58,12 +59,13 @@ def main():
         eng.setOption(E.OPT_TOPOLOGY, tp)
         eng.setOption(E.OPT_SHADE_BATCH, sb)
         eng.setOption(E.OPT_SWAP_BATCH, wb)
+        eng.setOption(E.OPT_TAIL_SPLIT, ts)
         if nodes is None:
             eng.buildBvh()
             nodes = eng.getBvhNodes()
         else:
             eng.setBvhNodes(nodes)
-        out = {"leaf": leaf, "box_mode": bm, "kernel": kv, "thr": th, "waves": wv, "lds": ld, "fmt": fm, "batch": lb, "occ": oc, "topo": tp, "shade": sb, "swap": wb}
+        out = {"leaf": leaf, "box_mode": bm, "kernel": kv, "thr": th, "waves": wv, "lds": ld, "fmt": fm, "batch": lb, "occ": oc, "topo": tp, "shade": sb, "swap": wb, "tail": ts}
         best = None
         for _ in range(args.frames):
             eng.render()

@@ -16,7 +16,7 @@ from rt_amd import engine as E  # noqa: E402
 from rt_amd import scenes  # noqa: E402
 
 NAMES = ["iters", "node_lanes", "stalled_lanes", "idle_lanes", "leaf_fires", "leaf_lanes", "leaf_prims", "refills",
-         "shade_lanes", "primary_lanes", "fetch_lanes", "node_iters", "retired_lanes"]
+         "shade_lanes", "primary_lanes", "fetch_lanes", "node_iters", "retired_lanes", "wait_lanes", "spin_polls"]
 
 
 def stats(eng):
@@ -29,6 +29,7 @@ def stats(eng):
     d["stalled_per_iter"] = d["stalled_lanes"] / it
     d["idle_per_iter"] = d["idle_lanes"] / it
     d["retired_per_iter"] = d["retired_lanes"] / it
+    d["wait_per_iter"] = d["wait_lanes"] / it
     d["leaf_lanes_per_fire"] = d["leaf_lanes"] / max(d["leaf_fires"], 1)
     d["leaf_prims_per_lane"] = d["leaf_prims"] / max(d["leaf_lanes"], 1)
     d["iters_per_leaf_fire"] = it / max(d["leaf_fires"], 1)
@@ -52,6 +53,7 @@ def main():
     ap.add_argument("--swap", type=int, default=None)
     ap.add_argument("--occ", type=int, default=None)
     ap.add_argument("--waves", type=int, default=None)
+    ap.add_argument("--tail", type=int, default=None)
     args = ap.parse_args()
     eng = rt_amd.PbrtEngine(args.nx, args.ny, args.spp, device=0)
     if args.threshold is not None:
@@ -61,7 +63,7 @@ def main():
     if args.leaf is not None:
         eng.setOption(E.OPT_LEAF_SIZE, args.leaf)
     for opt, v in ((E.OPT_KERNEL, args.kernel), (E.OPT_SHADE_BATCH, args.shade), (E.OPT_SWAP_BATCH, args.swap),
-                   (E.OPT_OCCUPANCY, args.occ), (E.OPT_WAVES_PER_CU, args.waves)):
+                   (E.OPT_OCCUPANCY, args.occ), (E.OPT_WAVES_PER_CU, args.waves), (E.OPT_TAIL_SPLIT, args.tail)):
         if v is not None:
             eng.setOption(opt, v)
     eng.setTriangles(scenes.heightfield(args.grid))
