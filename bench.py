@@ -58,6 +58,21 @@ def cpu_baseline_and_bytes(tris, nodes, cam_args, nx, ny, ns, depth, stride, thr
     return base, bytes_per_ray
 
 
+def valu_issue(kernel_s):
+    """VALU issue occupancy of the render kernel from the committed counter passes (profiles/r01_pmc_summary.json,
+    tools/pmc_passes.sh): wave64 VALU instructions x 4 cycles over the cycles of 1024 SIMDs.  Not measured live."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        k = [x for x in d if "k_persistent<0, 1, 1, 6>" in x][0]
+        v = {c: x["per_dispatch"] for c, x in d[k].items()}
+        cycles = v["GRBM_GUI_ACTIVE"] / 8.0  # summed over 8 XCDs
+        return {"source": "profiles/r01_pmc_summary.json", "valu_insts_per_launch": v["SQ_INSTS_VALU"],
+                "busy_frac": v["SQ_INSTS_VALU"] / 1024.0 * 4.0 / cycles,
+                "lane_utilisation": v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0)}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,8 +194,13 @@ def main():
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "kernel": "k_persistent<0,1,1,6> (render, quantized nodes, speculative)", "kernel_ms": kernel_s * 1e3,
-                    "algorithmic_bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_launch}
+                    "traffic": traffic, "kernel": "k_persistent<0,1,1,6> (render, quantized nodes, speculative, 8 rounds)",
+                    "kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_launch,
+                    # frac > 1 is not an error: SURVEY 8d prices every box test of a binary-tree traversal at 32 HBM
+                    # bytes, while the device BVH (30 MB of nodes) is served from L2 / Infinity Cache.
+                    # What binds the kernel is VALU issue; its measured share comes from the committed PMC passes.
+                    "measured_hbm_gbs": (traffic / kernel_s / 1e9) if traffic else None,
+                    "valu_issue": valu_issue(kernel_s)}
         line = {
             "metric": "Mrays/s (node) on 1M-tri BVH; ms/frame at 1080p",
             "value": value,

@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--leaf", type=ints, default=[2])
     ap.add_argument("--box-mode", type=ints, default=[0])
     ap.add_argument("--kernel", type=ints, default=[2])
-    ap.add_argument("--threshold", type=ints, default=[32])
+    ap.add_argument("--threshold", type=ints, default=[24])
     ap.add_argument("--waves", type=ints, default=[24])
     ap.add_argument("--lds", type=ints, default=[16])
     ap.add_argument("--fmt", type=ints, default=[1])
@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--topo", type=ints, default=[1])
     ap.add_argument("--shade", type=ints, default=[32])
     ap.add_argument("--swap", type=ints, default=[8])
-    ap.add_argument("--tail", type=ints, default=[2])
+    ap.add_argument("--tail", type=ints, default=[8])
     args = ap.parse_args()
     tris = scenes.heightfield(args.grid)
     eng = rt_amd.PbrtEngine(args.nx, args.ny, args.spp, device=0)
