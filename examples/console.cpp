@@ -1,0 +1,136 @@
+// examples/console.cpp -- the reference's console loop (main.cpp:68-332) over the PbrtEngine shim and the C++ scene
+// restatement, without the window: reads one command per line from stdin, prints what the reference prints.
+//   console                      interactive / scripted session on the default scene (needs an MI355X)
+//   console --dump-scene FILE    same loop, but `render` writes the flattened scene (148-byte records) to FILE, prints
+//                                "<n> <rand calls>" and exits: no GPU needed (tests compare it with scene_graph.py)
+// Commands kept: q | m <mesh> | camera posx|negx|posy|negy|posz|negz|info|aperture x|dist_to_focus [x] |
+//                render | render -cache | render status | render param nx ny ns | render hd |
+//                mx|my|mz|rx|ry|rz|s <x> | reset | radius.    GL-only commands are accepted and ignored.
+//   hipcc -std=c++17 -ffp-contract=off examples/console.cpp -Lrt_amd -lrt_amd -Wl,-rpath,'$ORIGIN/../rt_amd' -o examples/console
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "../rt_amd/csrc/rt_engine.hpp"
+#include "../rt_amd/csrc/rt_scene.hpp"
+
+using namespace rtscene;
+
+// make_bvh_nodes makes one rand() call per invocation (pbrt_engine.cu:335-368)
+static long long build_rand_calls(long long cnt) {
+    if (cnt <= 0) return 0;
+    if (cnt <= 2) return 1;
+    return 1 + build_rand_calls(cnt / 2) + build_rand_calls(cnt - cnt / 2);
+}
+
+struct GlCamera { // the fields __renderScene reads (include/RT/camera.h:32-47,110-159,245-272)
+    Vec3 pos{0, 0, 3}, front{0, 0, -1};
+    float zoom = 45.0f, dist_to_focus = 10.0f, aperture = 0.0f, speed = 2.5f;
+};
+
+int main(int argc, char **argv) {
+    CountedRand rng;
+    Collection meshes = default_scene(rng);
+    const bool dump = argc > 2 && std::string(argv[1]) == "--dump-scene";
+    const char *out_path = argc > 2 && std::string(argv[1]) == "--out" ? argv[2] : "./output.ppm";
+    long long rand_calls = rng.calls; // rand() position handed to the next build
+    GlCamera cam;
+    Mesh *curr = nullptr;
+    bool loop = true;
+    std::string line;
+    while (loop) {
+        std::cout << ">>>:";
+        if (!std::getline(std::cin, line)) break;
+        line = line.substr(0, 29); // cin.getline(input, 30), main.cpp:80
+        std::istringstream iss(line);
+        std::vector<std::string> tokens;
+        for (std::string t; iss >> t;) tokens.push_back(t);
+        if (tokens.empty()) continue;
+        try {
+            const std::string &first = tokens[0];
+            if (first == "q") {
+                std::cout << "bye, press any buttion to end.\n";
+                loop = false;
+            } else if (first == "m") {
+                auto it = meshes.find(tokens.at(1));
+                if (it == meshes.end()) {
+                    std::cout << "ERROR: Model " << tokens[1] << " not found.\n";
+                    continue;
+                }
+                curr = it->second.get();
+                std::cout << "setting model finished.\n";
+            } else if (first == "camera") {
+                const std::string &second = tokens.at(1);
+                auto look = [&](Vec3 p, Vec3 f) {
+                    cam.pos = p;
+                    cam.front = f;
+                };
+                if (second == "posx") look({3, 0, 0}, {-1, 0, 0});
+                else if (second == "negx") look({-3, 0, 0}, {1, 0, 0});
+                else if (second == "posy") look({0, 3, 0}, {0.1f, -1, 0.1f});
+                else if (second == "negy") look({0, -3, 0}, {-0.1f, 1, -0.1f});
+                else if (second == "posz") look({0, 0, 3}, {0, 0, -1});
+                else if (second == "negz") look({0, 0, -3}, {0, 0, 1});
+                else if (second == "info") {
+                    std::cout << cam.pos.x << " " << cam.pos.y << " " << cam.pos.z << std::endl;
+                    std::cout << cam.front.x << " " << cam.front.y << " " << cam.front.z << std::endl;
+                } else if (second == "aperture") cam.aperture = std::stof(tokens.at(2));
+                else if (second == "dist_to_focus") {
+                    if (tokens.size() > 2) {
+                        cam.dist_to_focus = std::stof(tokens[2]);
+                    } else {
+                        if (!curr) throw std::runtime_error("no model selected");
+                        const Vec3 d = cam.pos - curr->getPosition(); // getDistToFocus(Mesh*), camera.h:261-265
+                        cam.dist_to_focus = std::sqrt((d.x * d.x + d.y * d.y) + d.z * d.z);
+                        std::cout << "INFO: set camera distance_to_focus to " << cam.dist_to_focus << std::endl;
+                    }
+                } else if (second == "speed") {
+                    if (tokens.size() < 3) std::cout << "curr camera speed: " << cam.speed << std::endl;
+                    else cam.speed = std::stof(tokens[2]);
+                }
+            } else if (first == "render" && dump) {
+                std::vector<rt_triangle148> tris = gather(meshes);
+                std::ofstream(argv[2], std::ios::binary).write((const char *)tris.data(), (std::streamsize)(tris.size() * sizeof(rt_triangle148)));
+                std::cout << tris.size() << " " << rand_calls << "\n";
+                return 0;
+            } else if (first == "render") {
+                PbrtEngine &engine = PbrtEngine::getInstance(); // created on first use: the only thing that needs a GPU
+                if (tokens.size() >= 2 && tokens[1] == "status") {
+                    engine.checkStatus();
+                } else if (tokens.size() >= 2 && (tokens[1] == "param" || tokens[1] == "hd")) {
+                    const bool hd = tokens[1] == "hd";
+                    engine.setNx(hd ? 1280 : std::stoi(tokens.at(2)));
+                    engine.setNy(hd ? 720 : std::stoi(tokens.at(3)));
+                    engine.setNs(hd ? 100 : std::stoi(tokens.at(4)));
+                    if (engine.nXnYChanged()) engine.uponPixelNumChange();
+                    else engine.uponPixelNumChange(); // ns reaches the library through rt_resize as well
+                } else {
+                    const bool build = !(tokens.size() >= 2 && tokens[1] == "-cache");
+                    if (build) engine.setTriangles(gather(meshes));
+                    const float from[3] = {cam.pos.x, cam.pos.y, cam.pos.z};
+                    const float at[3] = {cam.pos.x + cam.front.x, cam.pos.y + cam.front.y, cam.pos.z + cam.front.z};
+                    engine.setCamera(from, at, cam.zoom, cam.dist_to_focus, cam.aperture);
+                    engine.rand_calls_before = rand_calls;
+                    engine.renderScene(build, out_path);
+                    engine.join();
+                    if (build) rand_calls += build_rand_calls((long long)engine.m_vecTriangles.size());
+                }
+            } else if (curr) {
+                if (first == "mx") curr->translateXCommand(std::stof(tokens.at(1)));
+                else if (first == "my") curr->translateYCommand(std::stof(tokens.at(1)));
+                else if (first == "mz") curr->translateZCommand(std::stof(tokens.at(1)));
+                else if (first == "rx") curr->rotationCommand(0, std::stof(tokens.at(1)));
+                else if (first == "ry") curr->rotationCommand(1, std::stof(tokens.at(1)));
+                else if (first == "rz") curr->rotationCommand(2, std::stof(tokens.at(1)));
+                else if (first == "s") curr->scaleCommand(std::stof(tokens.at(1)));
+                else if (first == "reset") curr->resetAll();
+                else if (first == "radius") std::cout << "radius => " << curr->getAverageRadius() << std::endl;
+            }
+        } catch (std::exception &e) {
+            std::cout << "Console Error: " << e.what() << std::endl;
+        }
+    }
+    std::cout << "Quitting this thread.\n";
+    return 0;
+}

@@ -178,6 +178,10 @@ int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *
  * is split over `world` contexts (RT_OPT_SHARD_RANK / RT_OPT_SHARD_WORLD). */
 int rt_test_tile_owner(int nx, int ny, int world, int32_t *owner);
 
+/* The library's sine / cosine (binary64 range reduction + Taylor, rounded once to float): what the
+ * host-side scene code (rt_scene.hpp, scene_graph.py) uses for glm::rotate so that both produce the same matrices. */
+int rt_test_sincosf(float x, float *s, float *c);
+
 /* Lane-occupancy counters of the last persistent-kernel launch (analysis builds only: `make STATS=1` builds
  * librt_amd_stats.so; the shipped library returns RT_E_UNSUPPORTED).  Layout: rt_amd/csrc/kernels.h kStat*. */
 int rt_test_trav_stats(rt_ctx *ctx, uint64_t out[16]);

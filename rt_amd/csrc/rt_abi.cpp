@@ -801,6 +801,15 @@ int rt_test_trav_stats(rt_ctx *c, uint64_t out[16]) {
 #endif
 }
 
+int rt_test_sincosf(float x, float *s, float *c) {
+    if (!s || !c) return RT_E_ARG;
+    double sd, cd;
+    sincos_sh((double)x, sd, cd);
+    *s = (float)sd;
+    *c = (float)cd;
+    return RT_OK;
+}
+
 int rt_test_tile_owner(int nx, int ny, int world, int32_t *owner) {
     if (nx <= 0 || ny <= 0 || world <= 0 || !owner) return RT_E_ARG;
     // the rule of tile_pixel() / k_persistent in kernels.hip: 8x8 tiles, row-major tile index g, owner = g % world

@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     "rt_set_bvh_nodes", "rt_get_bvh_nodes", "rt_default_materials", "rt_set_materials", "rt_set_camera",
     "rt_set_option", "rt_get_option", "rt_render", "rt_render_device", "rt_trace_primary", "rt_trace_rays",
     "rt_write_ppm", "rt_test_glibc_rand", "rt_test_introsort", "rt_test_build_bvh", "rt_test_wide_layout", "rt_test_tile_owner",
-    "rt_test_trav_stats",
+    "rt_test_trav_stats", "rt_test_sincosf",
 ]
 
 

@@ -51,10 +51,15 @@ class GlibcRand:
         return F(F(self.rand()) / F(2147483647))
 
 
+# glm is not in the reference's checkout (a system dependency, version unpinned): the operations below restate its
+# published float arithmetic (glm/detail/type_mat4x4.inl, glm/ext/matrix_transform.inl), column-major, in float32.
 def _translate(m: np.ndarray, v) -> np.ndarray:
-    """glm::translate(m, v): m[3] = m[0]*v.x + m[1]*v.y + m[2]*v.z + m[3]  (columns)."""
+    """glm::translate(m, v): m[3] = m[0]*v.x + m[1]*v.y + m[2]*v.z + m[3]  (columns, summed left to right)."""
     r = m.copy()
-    r[:, 3] = (m[:, 0] * F(v[0]) + m[:, 1] * F(v[1]) + m[:, 2] * F(v[2]) + m[:, 3]).astype(F)
+    acc = (m[:, 0] * F(v[0])).astype(F)
+    acc = (acc + (m[:, 1] * F(v[1])).astype(F)).astype(F)
+    acc = (acc + (m[:, 2] * F(v[2])).astype(F)).astype(F)
+    r[:, 3] = (acc + m[:, 3]).astype(F)
     return r
 
 
@@ -65,15 +70,54 @@ def _scale(m: np.ndarray, s) -> np.ndarray:
     return r
 
 
+def _matmul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """mat4 * mat4: column j = a[0]*b[j][0] + a[1]*b[j][1] + a[2]*b[j][2] + a[3]*b[j][3], summed left to right."""
+    r = np.zeros((4, 4), dtype=F)
+    for j in range(4):
+        acc = (a[:, 0] * b[0, j]).astype(F)
+        for k in range(1, 4):
+            acc = (acc + (a[:, k] * b[k, j]).astype(F)).astype(F)
+        r[:, j] = acc
+    return r
+
+
+def _sincos(x) -> tuple:
+    """The library's sine / cosine (rt_test_sincosf): the same values in this file and in rt_scene.hpp."""
+    s, c = C.c_float(), C.c_float()
+    rc = load_library().rt_test_sincosf(C.c_float(float(x)), C.byref(s), C.byref(c))
+    assert rc == 0
+    return F(s.value), F(c.value)
+
+
+def _rotate_identity(angle, axis) -> np.ndarray:
+    """glm::rotate(mat4(1), angle, axis): Rodrigues' matrix as glm writes it (axis normalised by the caller)."""
+    s, c = _sincos(angle)
+    ax = np.asarray(axis, dtype=F)
+    temp = ((F(1) - c) * ax).astype(F)
+    rot = np.zeros((3, 3), dtype=F)  # rot[col][row]
+    rot[0][0] = c + temp[0] * ax[0]
+    rot[0][1] = temp[0] * ax[1] + s * ax[2]
+    rot[0][2] = temp[0] * ax[2] - s * ax[1]
+    rot[1][0] = temp[1] * ax[0] - s * ax[2]
+    rot[1][1] = c + temp[1] * ax[1]
+    rot[1][2] = temp[1] * ax[2] + s * ax[0]
+    rot[2][0] = temp[2] * ax[0] + s * ax[1]
+    rot[2][1] = temp[2] * ax[1] - s * ax[0]
+    rot[2][2] = c + temp[2] * ax[2]
+    r = np.eye(4, dtype=F)
+    for col in range(3):  # Result[col] = I[0]*rot[col][0] + I[1]*rot[col][1] + I[2]*rot[col][2]
+        r[0:3, col] = rot[col]
+    return r
+
+
 def _apply(m: np.ndarray, p: np.ndarray) -> np.ndarray:
-    """vec3(m * vec4(p, 1)) for an (n, 3) array: glm sums column by column, x first."""
+    """vec3(m * vec4(p, 1)) for an (n, 3) array, as glm's mat4 * vec4 associates: (m0*x + m1*y) + (m2*z + m3*1)."""
     p = np.asarray(p, dtype=F).reshape(-1, 3)
     out = np.zeros_like(p)
     for r in range(3):
-        acc = (m[r, 0] * p[:, 0]).astype(F)
-        acc = (acc + (m[r, 1] * p[:, 1]).astype(F)).astype(F)
-        acc = (acc + (m[r, 2] * p[:, 2]).astype(F)).astype(F)
-        out[:, r] = (acc + m[r, 3]).astype(F)
+        add0 = ((m[r, 0] * p[:, 0]).astype(F) + (m[r, 1] * p[:, 1]).astype(F)).astype(F)
+        add1 = ((m[r, 2] * p[:, 2]).astype(F) + (m[r, 3] * F(1)).astype(F)).astype(F)
+        out[:, r] = (add0 + add1).astype(F)
     return out
 
 
@@ -100,14 +144,13 @@ class Mesh:
         self.translation = (self.translation + np.array([x, y, z], dtype=F)).astype(F)
 
     def rotation_command(self, axis: int, degrees: float):
-        """rotation{X,Y,Z}Command: R = glm::rotate(I, d / 180 * PI, axis) * R.  cos/sin are numpy's float32 here (the
-        reference's are MSVC's cosf/sinf): last-bit agreement of a rotated pose is not claimed."""
-        a = F(F(degrees) / F(180.0) * F(3.14159265358979323846))
-        c, s = F(np.cos(a)), F(np.sin(a))
-        r = np.eye(4, dtype=F)
-        i, j = [(1, 2), (2, 0), (0, 1)][axis]
-        r[i, i], r[i, j], r[j, i], r[j, j] = c, -s, s, c
-        self.rotation = (r @ self.rotation).astype(F)
+        """rotation{X,Y,Z}Command: R = glm::rotate(I, d / 180 * PI, axis) * R.  cos/sin are the library's (the
+        reference's are its C runtime's cosf/sinf): last-bit agreement of a rotated pose with the reference is not
+        claimed, agreement between this file and rt_scene.hpp is."""
+        a = F(float(F(degrees) / F(180.0)) * 3.1415926)  # getRadians: _d / 180.f * PI, PI the double 3.1415926 (mesh.h:38,297-299)
+        ax = [F(0), F(0), F(0)]
+        ax[axis] = F(1)
+        self.rotation = _matmul(_rotate_identity(a, ax), self.rotation)
 
     def reset_all(self):
         self.rotation = np.eye(4, dtype=F)
@@ -119,7 +162,10 @@ class Mesh:
         gives NaN, as the reference's 0/0 does."""
         if self.vertices.shape[0] == 0:
             return np.full(3, np.nan, dtype=F)
-        return (self.vertices.sum(axis=0, dtype=F) / F(self.vertices.shape[0])).astype(F)
+        acc = np.zeros(3, dtype=F)
+        for v in self.vertices:  # m_vec3Position += v.Position, in order
+            acc = (acc + v).astype(F)
+        return (acc / F(self.vertices.shape[0])).astype(F)
 
     def get_position(self) -> np.ndarray:
         """getPosition (mesh.h:267-272): model . centroid."""
@@ -147,7 +193,7 @@ class Mesh:
         w = self._who()
         m = np.eye(4, dtype=F)
         m = _translate(m, w.translation)
-        m = (m @ w.rotation).astype(F)
+        m = _matmul(m, w.rotation)
         return _scale(m, w.scale)
 
     def gen_triangles(self) -> np.ndarray:
@@ -219,7 +265,7 @@ def default_meshes():
     for a in range(-11, 11, 2):
         for b in range(-11, 11, 2):
             choose_mat = rng.drand48()
-            r = 0.2 + float(rng.drand48()) / 10  # `auto r` is a double (main.cpp:460)
+            r = 0.2 + float(F(rng.drand48()) / F(10))  # float / int is a float division; `auto r` is a double (main.cpp:460)
             cx = F(a + 0.2 * float(local_random()))  # x argument drawn first
             cz = F(b + 0.2 * float(local_random()))
             center = np.array([cx, F(r), cz], dtype=F)
@@ -230,9 +276,9 @@ def default_meshes():
                 radii.append(F(r))
                 flags.append(not (float(rng.drand48()) < 0.5))
                 if float(choose_mat) < 0.3:
-                    mats.append(int(10 + float(rng.drand48()) * 20))
+                    mats.append(int(F(10) + F(rng.drand48()) * F(20)))  # int + float * int: float arithmetic, then truncation
                 elif float(choose_mat) < 0.9:
-                    mats.append(int(30 + float(rng.drand48()) * 20))
+                    mats.append(int(F(30) + F(rng.drand48()) * F(20)))
                 else:
                     mats.append(7)
     for i, (c, r, m, flag) in enumerate(zip(centers, radii, mats, flags)):

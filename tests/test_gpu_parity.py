@@ -304,6 +304,39 @@ def test_cpp_host_example(oracle, tmp_path):
     assert (tmp_path / "output.ppm").read_bytes() == (tmp_path / "ref.ppm").read_bytes()
 
 
+def test_cpp_console_session_equals_the_python_one(oracle, tmp_path):
+    """examples/console.cpp (C++: real glibc rand(), rt_scene.hpp, the PbrtEngine shim) and rt_amd/console.py (numpy,
+    restated rand()) run the same scripted session on the default scene -- a posed mesh, two builds, a cached render
+    with a lens -- and leave the same output.ppm, byte for byte; the last frame is also the oracle's."""
+    import subprocess
+
+    from rt_amd import console as rc
+    from rt_amd import scene_graph as sg
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "console")
+    if not os.path.exists(exe):
+        pytest.fail("examples/console is not built: run __graft_entry__.build()")
+    script = ["camera posy", "render param 80 48 3", "render", "m c1", "ry 33", "my 0.75", "s 1.5", "m cube", "rz 20",
+              "camera posx", "render", "camera aperture 0.05", "camera dist_to_focus", "render -cache", "q"]
+    out = subprocess.run([exe], input="\n".join(script) + "\n", cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.count("PbrtEngine: rendering finished.") == 3 and "Console Error" not in out.stdout
+    meshes, calls = sg.default_meshes()
+    eng = rt_amd.PbrtEngine(device=0)
+    con = rc.Console(eng, meshes, calls, out_path=str(tmp_path / "py.ppm"))
+    for line in script:
+        assert "Console Error" not in con.execute(line)
+    assert (tmp_path / "output.ppm").read_bytes() == (tmp_path / "py.ppm").read_bytes()
+    tris = con.last_triangles
+    nodes = oracle.build_bvh(tris, calls + sg.build_rand_calls(tris.shape[0]))
+    assert nodes.tobytes() == eng.getBvhNodes().tobytes()
+    c = con.camera
+    ocam = oracle.camera(c.position, c.position + c.front, 40.0, 80 / 48, float(c.aperture), float(c.dist_to_focus))
+    fb_o, _ = oracle.render(tris, nodes, oracle.material_table(), ocam, 80, 48, 3, 50, mode=1)
+    assert con.last_frame.tobytes() == fb_o.tobytes()
+    eng.close()
+
+
 def test_error_behaviour():
     eng = rt_amd.PbrtEngine(32, 32, 1, device=0)
     with pytest.raises(rt_amd.RtError, match="no scene|no camera"):

@@ -237,3 +237,33 @@ def test_builder_continues_the_rand_sequence_like_the_oracle(oracle):
     tris, calls = sg.default_scene()
     for k in (0, calls, calls + sg.build_rand_calls(tris.shape[0])):
         assert engine.host_build_bvh(tris, k).tobytes() == oracle.build_bvh(tris, k).tobytes()
+
+
+def test_cpp_scene_code_matches_this_one(tmp_path):
+    """rt_scene.hpp through examples/console --dump-scene (C++ float arithmetic, the process's real rand()) against
+    scene_graph.py (numpy float32, restated rand()): the default scene, then a posed one (rotations about all three
+    axes, scale, translation, on a sphere, a cube instance, the shared cube and the light), byte for byte."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "console")
+    if not os.path.exists(exe):
+        pytest.skip("examples/console is not built: run __graft_entry__.build()")
+    poses = ["m c7", "rx 30", "ry -75.5", "rz 10", "s 1.7", "mx 0.25", "m c12", "ry 45", "mz -3", "m cube", "rz 45", "m light", "ry 12"]
+    for script in ([], poses):
+        dump = tmp_path / "scene.bin"
+        out = subprocess.run([exe, "--dump-scene", str(dump)], input="\n".join(script + ["render"]) + "\n", capture_output=True,
+                             text=True, timeout=60)
+        assert out.returncode == 0, out.stderr
+        n, calls = [int(x) for x in out.stdout.replace(">>>:", " ").split()[-2:]]
+        meshes, py_calls = sg.default_meshes()
+
+        class NoEngine:
+            pass
+
+        con = rc.Console(NoEngine(), meshes, py_calls, out_path=None)
+        for line in script:
+            assert "Error" not in con.execute(line)
+        tris = sg.gather(con.meshes.values())
+        assert (n, calls) == (tris.shape[0], py_calls)
+        assert dump.read_bytes() == tris.tobytes()
