@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--kernel", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stride", type=int, default=16)
+    ap.add_argument("--verify", action="store_true",
+                    help="after timing, rank 0 renders the whole frame alone and compares it with the assembled one")
     args = ap.parse_args()
 
     import numpy as np
@@ -101,12 +103,20 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the trace loop has no CPU fallback")
+    # RT_BENCH_REHEARSE=1: run the N > 1 code path on a box with ONE GPU (every rank on device 0, frame assembly over
+    # gloo).  For checking the multi-rank plumbing only; the numbers mean nothing.
+    rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import rt_amd
     from rt_amd import engine as E
@@ -156,14 +166,23 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=fb.device)
+        small = "cpu" if rehearse else fb.device
+        t = torch.tensor([elapsed], dtype=torch.float64, device=small)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        rr = torch.tensor([rays_local], dtype=torch.int64, device=fb.device)
+        rr = torch.tensor([rays_local], dtype=torch.int64, device=small)
         dist.all_reduce(rr)
         rays_total = int(rr.item())
     else:
         rays_total = rays_local
+
+    assembled_ok = None
+    if args.verify and world > 1 and rank == 0:
+        whole = torch.zeros_like(fb)
+        eng.setShard(0, 1)
+        eng.renderDevice(whole.data_ptr())
+        eng.setShard(rank, world)
+        assembled_ok = bool(torch.equal(whole, fb))
 
     if rank == 0:
         value = rays_total / elapsed / 1e6
@@ -182,6 +201,14 @@ def main():
             cpu, bytes_per_ray = cpu_baseline_and_bytes(tris, eng.getBvhNodes(), scenes.BENCH_CAMERA, args.nx, args.ny,
                                                         args.spp, args.depth, args.cpu_stride, threads)
         roof = None
+        bytes_source = "counted live by the oracle's ordered traversal on the CPU sample"
+        if bytes_per_ray is None:  # N > 1 or --no-cpu-baseline: the committed N = 1 count of the same scene and camera
+            try:
+                committed = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_line.json")))
+                bytes_per_ray = committed["roofline"]["algorithmic_bytes_per_ray"]
+                bytes_source = "profiles/r01_bench_line.json (N = 1 run of the same scene, camera, spp and depth)"
+            except Exception:
+                bytes_per_ray = None
         if bytes_per_ray is not None:
             achieved = bytes_per_ray * rays_per_launch / kernel_s / 1e9
             traffic = None
@@ -195,7 +222,8 @@ def main():
                     traffic = None
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "kernel": "k_persistent<0,1,1,6> (render, quantized nodes, speculative, 8 rounds)",
-                    "kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_launch,
+                    "kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_ray": bytes_per_ray, "bytes_per_ray_source": bytes_source,
+                    "rays_per_launch": rays_per_launch,
                     # frac > 1 is not an error: SURVEY 8d prices every box test of a binary-tree traversal at 32 HBM
                     # bytes, while the device BVH (30 MB of nodes) is served from L2 / Infinity Cache.
                     # What binds the kernel is VALU issue; its measured share comes from the committed PMC passes.
@@ -213,7 +241,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks on one GPU, gloo; not a measurement)",
             "config": {"workload": f"heightfield G={args.grid} ({tris.shape[0]} triangles), diffuse path tracing, "
                                    f"{nx}x{ny}, {args.spp} spp, max depth {args.depth}",
                        "triangles": int(tris.shape[0]), "frame": f"{nx}x{ny}", "spp": args.spp, "max_depth": args.depth,
@@ -223,6 +251,8 @@ def main():
             "cpu_baseline": cpu,
             "primary": prim,
         }
+        if assembled_ok is not None:
+            line["assembled_frame_equals_single_gpu_frame"] = assembled_ok
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
