@@ -32,6 +32,26 @@ struct GlCamera { // the fields __renderScene reads (include/RT/camera.h:32-47,1
 int main(int argc, char **argv) {
     CountedRand rng;
     Collection meshes = default_scene(rng);
+    // --obj NAME=FILE[:MAT] (any number, after the other options): meshes through the reference's own OBJ reader
+    for (int i = 1; i + 1 < argc; i++) {
+        if (std::string(argv[i]) != "--obj") continue;
+        const std::string spec = argv[i + 1];
+        const size_t eq = spec.find('='), colon = spec.rfind(':');
+        if (eq == std::string::npos) {
+            std::cerr << "--obj NAME=FILE[:MAT]\n";
+            return 2;
+        }
+        const bool has_mat = colon != std::string::npos && colon > eq;
+        std::ifstream in(spec.substr(eq + 1, has_mat ? colon - eq - 1 : std::string::npos));
+        std::vector<Vec3> v;
+        std::vector<unsigned> idx;
+        std::string err = "file not found or not good";
+        if (!in.good() || !load_obj(in, v, idx, err)) {
+            std::cerr << "ERROR: loading obj:(" << spec << ") " << err << "\n";
+            return 2;
+        }
+        registerModel(meshes, std::make_shared<Mesh>(spec.substr(0, eq), v, idx, has_mat ? std::atoi(spec.c_str() + colon + 1) : 0));
+    }
     const bool dump = argc > 2 && std::string(argv[1]) == "--dump-scene";
     const char *out_path = argc > 2 && std::string(argv[1]) == "--out" ? argv[2] : "./output.ppm";
     long long rand_calls = rng.calls; // rand() position handed to the next build

@@ -259,8 +259,15 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--out", default="./output.ppm")
+    ap.add_argument("--obj", action="append", default=[], metavar="NAME=FILE[:MAT]",
+                    help="add a mesh through the reference's own OBJ reader (scene_graph.load_obj)")
     args = ap.parse_args(argv)
     meshes, calls = sg.default_meshes()
+    for spec in args.obj:
+        name, _, rest = spec.partition("=")
+        path, _, mat = rest.rpartition(":") if ":" in rest else (rest, "", "0")
+        with open(path, newline="") as fh:
+            meshes.append(sg.mesh_from_obj(name, fh.read(), int(mat)))
     con = Console(PbrtEngine(device=args.device), meshes, calls, out_path=args.out)
     con.run()
 

@@ -10,7 +10,9 @@
 #pragma once
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
+#include <istream>
 #include <map>
 #include <memory>
 #include <string>
@@ -207,6 +209,46 @@ class FlyWeight : public Mesh { // mesh.h:591-622
   private:
     MESH_PTR _orig;
 };
+
+// The reference's hand-rolled OBJ reader (include/RT/triangle.h:604-676): "v x y z" and
+// "f a/b/c a/b/c a/b/c [a/b/c]" lines only, 1-based indices, quads split (1,2,3) + (1,3,4); getline(buffer, 255), so a
+// last line without a newline is dropped; any other face syntax is an error.  Errors come back as text, not exit().
+inline bool load_obj(std::istream &in, std::vector<Vec3> &vertices, std::vector<unsigned> &indices, std::string &err) {
+    std::string line;
+    while (std::getline(in, line)) {
+        if (in.eof()) break; // no newline after it: the reference's loop tests eof() before using the buffer
+        if (line.size() > 254) {
+            err = "OBJ line longer than 254 characters";
+            return false;
+        }
+        const char *buffer = line.c_str();
+        if (line.size() >= 2 && buffer[0] == 'v' && buffer[1] == ' ') {
+            float f1, f2, f3;
+            if (std::sscanf(buffer, "v %f %f %f", &f1, &f2, &f3) != 3) {
+                err = "ERROR: vertex not in wanted format in OBJLoader";
+                return false;
+            }
+            vertices.push_back(Vec3{f1, f2, f3});
+        } else if (line.size() >= 2 && buffer[0] == 'f' && buffer[1] == ' ') {
+            int d1[3], d2[3], d3[3], d4[3];
+            const int nt = std::sscanf(buffer, "f %d/%d/%d %d/%d/%d %d/%d/%d %d/%d/%d", &d1[0], &d1[1], &d1[2], &d2[0], &d2[1],
+                                       &d2[2], &d3[0], &d3[1], &d3[2], &d4[0], &d4[1], &d4[2]);
+            if (nt != 12 && nt != 9) {
+                err = "ERROR: I don't know the format of that FaceMtl";
+                return false;
+            }
+            const int tri[2][3] = {{d1[0], d2[0], d3[0]}, {d1[0], d3[0], d4[0]}};
+            for (int t = 0; t < (nt == 12 ? 2 : 1); t++)
+                for (int k = 0; k < 3; k++) indices.push_back((unsigned)(tri[t][k] - 1)); // f.x() - 1, pbrt_engine.cu:254-258
+        }
+    }
+    for (unsigned i : indices)
+        if (i >= vertices.size()) {
+            err = "OBJ face index out of range";
+            return false;
+        }
+    return true;
+}
 
 using Collection = std::map<std::string, MESH_PTR>; // meshesCollection, main.cpp:46; std::map: name order
 inline void registerModel(Collection &c, const MESH_PTR &m) { c.emplace(m->m_strName, m); } // first name wins, mesh.h:232-239

@@ -222,6 +222,76 @@ class FlyWeight(Mesh):
             self.orig.top = None
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's hand-rolled OBJ reader (include/RT/triangle.h:604-676): real meshes without
+# assimp.  Only "v x y z" and "f a/b/c a/b/c a/b/c [a/b/c]" lines count (1-based vertex indices; a quad becomes
+# (1,2,3) + (1,3,4)); any other face syntax is an error, as there.  Lines are read with getline(buffer, 255): a last
+# line without a newline is dropped (the loop tests eof() first), a line of 255+ characters is refused here (the
+# reference would spin on the stream's fail bit).
+_FLOAT = __import__("re").compile(r"[+-]?(?:\d+\.?\d*(?:[eE][+-]?\d+)?|\.\d+(?:[eE][+-]?\d+)?|inf(?:inity)?|nan)", __import__("re").I)
+_INT = __import__("re").compile(r"[+-]?\d+")
+
+
+def _scan(buf: str, fmt) -> list:
+    """sscanf for the two formats the reader uses: fmt is a list of ' ' (any white space), '%d', '%f' or a literal
+    character; returns the conversions made before the first mismatch."""
+    pos, out = 0, []
+    for f in fmt:
+        if f == " ":
+            while pos < len(buf) and buf[pos].isspace():
+                pos += 1
+        elif f in ("%d", "%f"):
+            while pos < len(buf) and buf[pos].isspace():
+                pos += 1
+            m = (_INT if f == "%d" else _FLOAT).match(buf, pos)
+            if not m:
+                break
+            out.append(int(m.group()) if f == "%d" else F(float(m.group())))
+            pos = m.end()
+        else:
+            if pos >= len(buf) or buf[pos] != f:
+                break
+            pos += 1
+    return out
+
+
+_V_FMT = ["v", " ", "%f", " ", "%f", " ", "%f"]
+_F_FMT = ["f"] + [x for _ in range(4) for x in (" ", "%d", "/", "%d", "/", "%d")]
+
+
+def load_obj(text: str):
+    """loadObj on the text of a file.  Returns (vertices (n, 3) float32, faces (m, 3) int, 1-based as stored)."""
+    vertices, faces = [], []
+    lines = text.split("\n")
+    for line in lines[:-1]:  # what follows the last newline is never processed (eof() ends the loop first)
+        if len(line) > 254:
+            raise ValueError("OBJ line longer than 254 characters")
+        if len(line) >= 2 and line[0] == "v" and line[1] == " ":
+            v = _scan(line, _V_FMT)
+            if len(v) != 3:
+                raise ValueError("ERROR: vertex not in wanted format in OBJLoader")
+            vertices.append(v)
+        elif len(line) >= 2 and line[0] == "f" and line[1] == " ":
+            d = _scan(line, _F_FMT)
+            if len(d) == 12:
+                faces.append([d[0], d[3], d[6]])
+                faces.append([d[0], d[6], d[9]])
+            elif len(d) == 9:
+                faces.append([d[0], d[3], d[6]])
+            else:
+                raise ValueError("ERROR: I don't know the format of that FaceMtl")
+    return np.asarray(vertices, dtype=F).reshape(-1, 3), np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+
+
+def mesh_from_obj(name: str, text: str, mat_type: int = 0) -> Mesh:
+    """A Mesh over an OBJ file's triangles (indices made 0-based, as loadTriangleFromMesh's `f.x() - 1`,
+    pbrt_engine.cu:254-258)."""
+    v, f = load_obj(text)
+    if f.size and (f.min() < 1 or f.max() > v.shape[0]):
+        raise ValueError("OBJ face index out of range")
+    return Mesh(name, v, (f - 1).reshape(-1), mat_type=mat_type)
+
+
 def gather(meshes) -> np.ndarray:
     """__genTrianglesFromScene (pbrt_engine.cu:167-178) over a std::map-ordered (name-sorted) collection."""
     by_name = {}

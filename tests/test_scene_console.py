@@ -267,3 +267,63 @@ def test_cpp_scene_code_matches_this_one(tmp_path):
         tris = sg.gather(con.meshes.values())
         assert (n, calls) == (tris.shape[0], py_calls)
         assert dump.read_bytes() == tris.tobytes()
+
+
+OBJ = """# a tetrahedron and a quad
+v 0 0 0
+v 1.5 0 0
+v 0 2e0 0
+v 0 0 -.75
+vt 0 0
+vn 0 0 1
+v -1 -1 5   trailing
+v 1 -1 5
+v 1 1 5
+v -1 1 5
+f 1/1/1 2/1/1 3/1/1
+f 1/1/1 3/1/1 4/1/1
+f 1/1/1 4/1/1 2/1/1
+f 2/1/1 4/1/1 3/1/1
+f 5/1/1 6/1/1 7/1/1 8/1/1
+f 1/2/3   2/2/3 3/9/9
+f 1/1/1 2/1/1 4/1/1"""
+
+
+def test_obj_reader_follows_the_reference(tmp_path):
+    """loadObj (include/RT/triangle.h:604-676) restated: v / f lines only, quads split (1,2,3) + (1,3,4), the last line
+    without a newline dropped, every other face syntax an error; the C++ reader (real sscanf) gives the same records."""
+    import os
+    import subprocess
+
+    v, f = sg.load_obj(OBJ)
+    assert v.shape == (8, 3) and v[2, 1] == 2.0 and v[3, 2] == np.float32(-0.75) and v[4, 2] == 5.0
+    assert f.tolist() == [[1, 2, 3], [1, 3, 4], [1, 4, 2], [2, 4, 3], [5, 6, 7], [5, 7, 8], [1, 2, 3]]
+    assert sg.load_obj(OBJ + "\n")[1].shape[0] == 8  # with the newline the last face counts
+    for bad in ("f 1 2 3\n", "f 1//1 2//1 3//1\n", "f 1/1/1 2/1/1\n", "v 1 2\n", "v a b c\n"):
+        with pytest.raises(ValueError):
+            sg.load_obj(bad)
+    with pytest.raises(ValueError, match="out of range"):
+        sg.mesh_from_obj("x", "v 0 0 0\nf 1/1/1 2/1/1 3/1/1\n")
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "console")
+    if not os.path.exists(exe):
+        pytest.skip("examples/console is not built: run __graft_entry__.build()")
+    path = tmp_path / "t.obj"
+    path.write_bytes(OBJ.encode())
+    dump = tmp_path / "s.bin"
+    out = subprocess.run([exe, "--dump-scene", str(dump), "--obj", f"tet={path}:8"], input="m tet\nry 20\ns 0.5\nrender\n",
+                         capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    meshes, calls = sg.default_meshes()
+
+    class NoEngine:
+        pass
+
+    con = rc.Console(NoEngine(), meshes + [sg.mesh_from_obj("tet", OBJ, 8)], calls, out_path=None)
+    for line in ("m tet", "ry 20", "s 0.5"):
+        assert "Error" not in con.execute(line)
+    tris = sg.gather(con.meshes.values())
+    assert tris.shape[0] == 689 + 7 and dump.read_bytes() == tris.tobytes()
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nf 1 2 3\n")
+    out = subprocess.run([exe, "--dump-scene", str(dump), "--obj", f"b={bad}"], input="render\n", capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2 and "I don't know the format of that FaceMtl" in out.stderr
