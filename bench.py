@@ -24,11 +24,22 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline_and_bytes(tris, nodes, cam_args, nx, ny, ns, depth, stride, threads):
     """Rank 0, N=1 only.  Times the CPU oracle (the reference's visit pattern: full DFS, no early-out, pairwise
-    merge -- the reference has no CPU path) on a bounded pixel lattice of the same workload, and
-    counts the box / triangle tests of an ordered, t-shrinking traversal of the same binary tree on the same
-    rays, which define the algorithmic bytes per ray B = 32*N_box + 48*N_tri + 36."""
+    merge -- the reference has no CPU path) on a bounded pixel lattice of the same workload, on all the
+    cores this process may use and on one thread (a 16x sparser lattice), and counts the box / triangle tests of an
+    ordered, t-shrinking traversal of the same binary tree on the same rays, which define the algorithmic bytes per
+    ray B = 32*N_box + 48*N_tri + 36."""
     from tests import oracle_lib  # the oracle is the checker / reported baseline here, never the product path
 
     o = oracle_lib.load()
@@ -40,6 +51,9 @@ def cpu_baseline_and_bytes(tris, nodes, cam_args, nx, ny, ns, depth, stride, thr
     t1 = time.perf_counter()
     _, c_ref = o.render(tris, nodes, mats, cam, nx, ny, ns, depth, mode=0, threads=threads, lattice=lat)
     t2 = time.perf_counter()
+    s1 = 4 * stride
+    _, c_one = o.render(tris, nodes, mats, cam, nx, ny, ns, depth, mode=0, threads=1, lattice=(s1 // 2, s1 // 2, s1, s1))
+    t3 = time.perf_counter()
     assert c_ord.rays == c_ref.rays
     n_box = c_ord.box_tests / c_ord.rays
     n_tri = c_ord.tri_tests / c_ord.rays
@@ -52,6 +66,9 @@ def cpu_baseline_and_bytes(tris, nodes, cam_args, nx, ny, ns, depth, stride, thr
         "sample": f"every {stride}th pixel of every {stride}th row of the same {nx}x{ny} frame at {ns} spp, depth {depth} "
                   f"({c_ref.rays} rays), reference visit pattern ({c_ref.box_tests / c_ref.rays:.0f} box + "
                   f"{c_ref.tri_tests / c_ref.rays:.1f} tri tests/ray), {t2 - t1:.1f} s",
+        "cpu_model": cpu_model(),
+        "one_thread_value": c_one.rays / (t3 - t2) / 1e6,
+        "one_thread_sample": f"every {s1}th pixel of every {s1}th row ({c_one.rays} rays), {t3 - t2:.1f} s",
         "ordered_value": c_ord.rays / (t1 - t0) / 1e6,
         "ordered_tests_per_ray": {"box": n_box, "tri": n_tri},
     }
@@ -87,7 +104,7 @@ def main():
     ap.add_argument("--box-mode", type=int, default=None)
     ap.add_argument("--kernel", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-stride", type=int, default=16)
+    ap.add_argument("--cpu-stride", type=int, default=8, help="CPU baseline lattice: every n-th pixel of every n-th row")
     ap.add_argument("--verify", action="store_true",
                     help="after timing, rank 0 renders the whole frame alone and compares it with the assembled one")
     args = ap.parse_args()
