@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--kernel", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stride", type=int, default=8, help="CPU baseline lattice: every n-th pixel of every n-th row")
+    ap.add_argument("--sample-shard", action="store_true",
+                    help="N > 1: split the SAMPLES of one fixed-size frame over ranks (salted streams, summed with one "
+                         "all-reduce; SURVEY 8e's non-parity mode, strong scaling) instead of the tiles of a growing frame")
     ap.add_argument("--verify", action="store_true",
                     help="after timing, rank 0 renders the whole frame alone and compares it with the assembled one")
     args = ap.parse_args()
@@ -140,10 +143,15 @@ def main():
     from rt_amd import scenes
 
     # weak scaling: pixels grow with N at fixed aspect
-    s = math.sqrt(world)
+    sample_shard = args.sample_shard and world > 1
+    s = 1.0 if sample_shard else math.sqrt(world)
     nx, ny = int(round(args.nx * s)), int(round(args.ny * s))
     tris = scenes.heightfield(args.grid)
-    eng = rt_amd.PbrtEngine(nx, ny, args.spp, device=local_rank)
+    ns_local, salt = E.sample_shard(rank, world, args.spp) if sample_shard else (args.spp, 0)
+    eng = rt_amd.PbrtEngine(nx, ny, ns_local, device=local_rank)
+    if sample_shard:
+        eng.setOption(E.OPT_SEED_SALT, salt)
+        eng.setOption(E.OPT_RAW_SUM, 1)
     if args.leaf is not None:
         eng.setOption(E.OPT_LEAF_SIZE, args.leaf)
     if args.box_mode is not None:
@@ -156,13 +164,17 @@ def main():
     build_s = time.perf_counter() - t0
     eng.setMaxDepth(args.depth)
     eng.setCamera(**scenes.BENCH_CAMERA)
-    eng.setShard(rank, world)
+    if not sample_shard:
+        eng.setShard(rank, world)
+    kk = float(np.float32(1.0 / float(np.float32(args.spp))))
     fb = torch.zeros((ny, nx, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
 
     def step():
         st = eng.renderDevice(fb.data_ptr())
         if world > 1:
-            dist.all_reduce(fb)  # frame assembly: x + 0 is exact
+            dist.all_reduce(fb)  # frame assembly: x + 0 is exact (tiles) / sums of clamped samples (sample shards)
+            if sample_shard:
+                fb.mul_(kk).clamp_(max=1.0)
             torch.cuda.synchronize()  # the next frame's memset runs on the library's own stream
         return st.rays, st.kernel_ms
 
@@ -194,7 +206,7 @@ def main():
         rays_total = rays_local
 
     assembled_ok = None
-    if args.verify and world > 1 and rank == 0:
+    if args.verify and world > 1 and rank == 0 and not sample_shard:
         whole = torch.zeros_like(fb)
         eng.setShard(0, 1)
         eng.renderDevice(whole.data_ptr())
@@ -255,14 +267,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if sample_shard else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks on one GPU, gloo; not a measurement)",
             "config": {"workload": f"heightfield G={args.grid} ({tris.shape[0]} triangles), diffuse path tracing, "
                                    f"{nx}x{ny}, {args.spp} spp, max depth {args.depth}",
                        "triangles": int(tris.shape[0]), "frame": f"{nx}x{ny}", "spp": args.spp, "max_depth": args.depth,
-                       "parallelism": f"tile-interleaved x{world}", "bvh_build_s": build_s,
+                       "parallelism": (f"sample-pass x{world} (salted streams; not the parity path)" if sample_shard
+                                       else f"tile-interleaved x{world}"), "bvh_build_s": build_s,
                        "wide_nodes": int(eng.last_stats.wide_nodes), "lds_stack_entries": int(eng.last_stats.stack_entries)},
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -136,10 +136,15 @@ enum {
                                     rt_get_bvh_nodes always returns the reference's tree. */
     RT_OPT_SHADE_BATCH = 15,     /* kernel 3: lanes with shading work queued that end a traversal phase */
     RT_OPT_SWAP_BATCH = 16,      /* kernel 3: lanes waiting to exchange their two paths that trigger the exchange */
-    RT_OPT_TAIL_SPLIT = 17       /* kernel 1/2 render: the frame is walked in this many rounds (1..63, at most ns; default 8),
+    RT_OPT_TAIL_SPLIT = 17,      /* kernel 1/2 render: the frame is walked in this many rounds (1..63, at most ns; default 8),
                                     each running ns/rounds samples of every pixel and handing the pixel's state on to
                                     whichever lane takes it next round, so that the frame ends on fractions of a pixel
                                     instead of whole pixels; 1 = off.  Same image either way. */
+    /* Sample-pass sharding (NOT a parity path -- the reference's per-pixel stream is serial over samples,
+     * so splitting a pixel's samples over GPUs needs other streams): */
+    RT_OPT_SEED_SALT = 18,       /* added to the per-pixel seed 1995 + pixel_index (default 0 = the reference's streams) */
+    RT_OPT_RAW_SUM = 19          /* 1: the frame holds per-pixel SUMS of the (per-sample clamped) samples instead of the
+                                    clamped mean, so that ranks' frames can be added and divided by the total count */
 };
 int rt_set_option(rt_ctx *ctx, int option, int64_t value);
 int rt_get_option(rt_ctx *ctx, int option, int64_t *value);

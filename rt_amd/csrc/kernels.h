@@ -24,6 +24,8 @@ struct KernelFrame {
     int n_local_tiles; // tiles this context renders = grid size
     int shard_rank, shard_world;
     unsigned long long *ray_counter;
+    unsigned long long seed_salt; // added to the reference's per-pixel seed 1995 + pixel_index; 0 = the reference's streams
+    int raw_sum;                  // 1: write the per-pixel sum of (clamped) samples, not the clamped mean
 };
 
 hipError_t launch_trace_primary(const KernelScene &S, const KernelFrame &F, int stack_entries, int32_t *ids, float *ts,

@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(64) k_trace_primary(KernelScene S, KernelFrame
     if (in) {
         int pixel_index = j * F.nx + i;
         Rng g;
-        rng_init(g, (uint64_t)(1995 + pixel_index)); // pbrt_engine.cu:580
+        rng_init(g, (uint64_t)(1995 + pixel_index) + F.seed_salt); // pbrt_engine.cu:580
         Ray r = primary_ray(F.cam, i, j, F.nx, F.ny, g);
         Hit h = closest_hit(S.nodes, S.prims, r, s_stack + threadIdx.x);
         nr = 1;
@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(64) k_render(KernelScene S, KernelFrame F, flo
     if (in) {
         const int pixel_index = j * F.nx + i;
         Rng g;
-        rng_init(g, (uint64_t)(1995 + pixel_index));
+        rng_init(g, (uint64_t)(1995 + pixel_index) + F.seed_salt);
         V3 col = mk(0, 0, 0);
         int k = 0;
         int bounce = 0;
@@ -499,11 +499,11 @@ __global__ void __launch_bounds__(64) k_render(KernelScene S, KernelFrame F, flo
                 fresh = true;
             }
         }
-        { // col /= float(ns): multiply by float(1.0/ns), vec3.h:158-165
+        if (!F.raw_sum) { // col /= float(ns): multiply by float(1.0/ns), vec3.h:158-165
             float kk = (float)(1.0 / (double)(float)F.ns);
             col = mk(col.x * kk, col.y * kk, col.z * kk);
+            clip_color(col); // :591-593
         }
-        clip_color(col); // :591-593
         fb[3 * (size_t)pixel_index + 0] = col.x;
         fb[3 * (size_t)pixel_index + 1] = col.y;
         fb[3 * (size_t)pixel_index + 2] = col.z;
@@ -862,9 +862,11 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                     col = vadd(col, thr);
                     k++;
                     if (k == F.ns) {
-                        float kk = (float)(1.0 / (double)(float)F.ns);
-                        col = mk(col.x * kk, col.y * kk, col.z * kk);
-                        clip_color(col);
+                        if (!F.raw_sum) {
+                            float kk = (float)(1.0 / (double)(float)F.ns);
+                            col = mk(col.x * kk, col.y * kk, col.z * kk);
+                            clip_color(col);
+                        }
                         fb[3 * pixel_index + 0] = col.x;
                         fb[3 * pixel_index + 1] = col.y;
                         fb[3 * pixel_index + 2] = col.z;
@@ -914,7 +916,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                         // this round runs samples up to (round + 1) * ns / rounds; the last round ends at ns
                         yield_k = round + 1u < rounds ? (int)(((uint64_t)(round + 1u) * (uint64_t)F.ns) / rounds) : F.ns;
                         if (round == 0u) {
-                            rng_init(g, (uint64_t)(1995 + pj * F.nx + pi));
+                            rng_init(g, (uint64_t)(1995 + pj * F.nx + pi) + F.seed_salt);
                             col = mk(0, 0, 0);
                             k = 0;
                             has_pixel = true;
@@ -1134,9 +1136,12 @@ __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, 
                 pw.col = vadd(pw.col, pw.thr);
                 pw.k++;
                 if (pw.k == F.ns) {
-                    const float kk = (float)(1.0 / (double)(float)F.ns);
-                    V3 c = mk(pw.col.x * kk, pw.col.y * kk, pw.col.z * kk);
-                    clip_color(c);
+                    V3 c = pw.col;
+                    if (!F.raw_sum) {
+                        const float kk = (float)(1.0 / (double)(float)F.ns);
+                        c = mk(pw.col.x * kk, pw.col.y * kk, pw.col.z * kk);
+                        clip_color(c);
+                    }
                     const size_t pixel_index = (size_t)(pw.pij >> 16) * (size_t)F.nx + (size_t)(pw.pij & 0xFFFFu);
                     fb[3 * pixel_index + 0] = c.x;
                     fb[3 * pixel_index + 1] = c.y;
@@ -1163,7 +1168,7 @@ __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, 
                     const int pi = tx * 8 + (int)(within & 7u), pj = ty * 8 + (int)(within >> 3);
                     if (pi < F.nx && pj < F.ny) { // ragged edge tiles: the slot is simply dropped
                         pw.pij = ((uint32_t)pj << 16) | (uint32_t)pi;
-                        rng_init(pw.g, (uint64_t)(1995 + pj * F.nx + pi));
+                        rng_init(pw.g, (uint64_t)(1995 + pj * F.nx + pi) + F.seed_salt);
                         pw.col = mk(0, 0, 0);
                         pw.k = 0;
                         need_primary = true;

@@ -35,6 +35,8 @@ struct rt_ctx {
     uint32_t *d_ring_state = nullptr, *d_ring_flag = nullptr;
     size_t ring_items = 0;
     uint32_t frame_id = 0;
+    unsigned long long seed_salt = 0;
+    int raw_sum = 0;
     int refill_threshold = 24, waves_per_cu = 24, lds_stack = 16, node_format = 1, leaf_batch = 16, occupancy = 6, topology = 1;
     int n_cus = 256;
     unsigned int *d_bands = nullptr;
@@ -220,6 +222,8 @@ void fill_frame(rt_ctx *c, KernelFrame &F) {
     F.shard_world = c->shard_world;
     F.n_local_tiles = (int)((total - c->shard_rank + c->shard_world - 1) / c->shard_world);
     F.ray_counter = c->d_counter;
+    F.seed_salt = c->seed_salt;
+    F.raw_sum = c->raw_sum;
 }
 
 KernelScene scene_of(rt_ctx *c) {
@@ -553,6 +557,13 @@ int rt_set_option(rt_ctx *c, int option, int64_t value) {
         if (value < 1 || value > 64) return fail(c, RT_E_ARG, "swap batch 1..64");
         c->swap_batch = (int)value;
         return RT_OK;
+    case RT_OPT_SEED_SALT:
+        if (value < 0) return fail(c, RT_E_ARG, "seed salt must not be negative");
+        c->seed_salt = (unsigned long long)value;
+        return RT_OK;
+    case RT_OPT_RAW_SUM:
+        c->raw_sum = value ? 1 : 0;
+        return RT_OK;
     case RT_OPT_TAIL_SPLIT:
         if (value < 1 || value > 63) return fail(c, RT_E_ARG, "rounds 1..63");
         c->tail_split = (int)value;
@@ -587,6 +598,8 @@ int rt_get_option(rt_ctx *c, int option, int64_t *value) {
     case RT_OPT_SHADE_BATCH: *value = c->shade_batch; return RT_OK;
     case RT_OPT_SWAP_BATCH: *value = c->swap_batch; return RT_OK;
     case RT_OPT_TAIL_SPLIT: *value = c->tail_split; return RT_OK;
+    case RT_OPT_SEED_SALT: *value = (int64_t)c->seed_salt; return RT_OK;
+    case RT_OPT_RAW_SUM: *value = c->raw_sum; return RT_OK;
     default: return fail(c, RT_E_ARG, "unknown option");
     }
 }

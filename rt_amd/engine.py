@@ -38,7 +38,7 @@ assert MAT_DTYPE.itemsize == 20
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_LIGHT = 0, 1, 2, 3
 OPT_MAX_DEPTH, OPT_HONOR_VFOV, OPT_LEAF_SIZE, OPT_BOX_MODE, OPT_SHARD_RANK, OPT_SHARD_WORLD, OPT_KERNEL = 1, 2, 3, 4, 5, 6, 7
 OPT_REFILL_THRESHOLD, OPT_WAVES_PER_CU, OPT_LDS_STACK, OPT_NODE_FORMAT, OPT_LEAF_BATCH, OPT_OCCUPANCY, OPT_TOPOLOGY = 8, 9, 10, 11, 12, 13, 14
-OPT_SHADE_BATCH, OPT_SWAP_BATCH, OPT_TAIL_SPLIT = 15, 16, 17
+OPT_SHADE_BATCH, OPT_SWAP_BATCH, OPT_TAIL_SPLIT, OPT_SEED_SALT, OPT_RAW_SUM = 15, 16, 17, 18, 19
 
 
 class RtStats(C.Structure):
@@ -181,6 +181,22 @@ def write_ppm(path: str, fb: np.ndarray) -> None:
     rc = lib.rt_write_ppm(path.encode(), _ptr(fb), nx, ny)
     if rc:
         raise RtError(f"rt_write_ppm failed ({rc})")
+
+
+def sample_shard(rank: int, world: int, ns_total: int):
+    """Sample-pass sharding, the non-parity multi-GPU mode: rank r renders the WHOLE frame with
+    ns_total / world samples (the first ranks take the remainder) from its own streams (seed salt r << 32) and writes
+    per-pixel sums (OPT_RAW_SUM); the sums are added over ranks (all-reduce) and finished by assemble_sample_shards.
+    Valid because the reference clamps per sample, so the clamped samples simply add up.  Returns (ns_local, salt)."""
+    ns_local = ns_total // world + (1 if rank < ns_total % world else 0)
+    return ns_local, rank << 32
+
+
+def assemble_sample_shards(sum_fb: np.ndarray, ns_total: int) -> np.ndarray:
+    """col /= float(ns) as the reference does it (multiply by float(1.0 / ns), vec3.h:158-165), then the final clamp."""
+    kk = np.float32(1.0 / float(np.float32(ns_total)))
+    out = (np.asarray(sum_fb, dtype=np.float32) * kk).astype(np.float32)
+    return np.where(out.astype(np.float64) > 1.0, np.float32(1.0), out).astype(np.float32)
 
 
 class PbrtEngine:

@@ -239,6 +239,38 @@ def test_tail_split_does_not_change_the_image(oracle, kernel, tail, ns, waves, w
     eng.close()
 
 
+def test_sample_pass_sharding_mode():
+    """SURVEY.md 8e's second mode (not a parity path).  (1) With one rank and salt 0 the raw sums, finished on the
+    host, ARE the normal image, bit for bit.  (2) Two ranks x 32 samples from salted streams, summed, are as close to
+    a converged image as one rank x 64 samples (PSNR within 1 dB), and differ from it (other streams)."""
+    tris, cam, nx, ny, depth = scenes.heightfield(64), scenes.BENCH_CAMERA, 160, 90, 8
+    eng = _engine(tris, nx, ny, 64, depth, cam)
+    normal = eng.render()
+    eng.setOption(engine.OPT_RAW_SUM, 1)
+    raw = eng.render()
+    assert engine.assemble_sample_shards(raw, 64).tobytes() == normal.tobytes()
+    total = np.zeros_like(raw)
+    for r in range(2):
+        ns_local, salt = engine.sample_shard(r, 2, 64)
+        assert ns_local == 32
+        eng.setNs(ns_local)
+        eng.setOption(engine.OPT_SEED_SALT, salt)
+        total += eng.render()
+    sharded = engine.assemble_sample_shards(total, 64)
+    eng.setOption(engine.OPT_RAW_SUM, 0)
+    eng.setOption(engine.OPT_SEED_SALT, 7 << 32)
+    eng.setNs(2048)
+    converged = eng.render()
+    eng.close()
+
+    def psnr(a):
+        return 10.0 * np.log10(1.0 / np.mean((a.astype(np.float64) - converged.astype(np.float64)) ** 2))
+
+    assert sharded.tobytes() != normal.tobytes()
+    assert abs(psnr(sharded) - psnr(normal)) < 1.0, (psnr(sharded), psnr(normal))
+    assert psnr(sharded) > 20.0
+
+
 def test_injected_nodes_and_cached_render(oracle):
     """rt_set_bvh_nodes with the oracle's node array ("render -cache" reuses the built scene)."""
     tris = scenes.heightfield(20)
