@@ -557,6 +557,18 @@ __device__ __forceinline__ void trav_begin(Trav &T, const Ray &r) {
     T.sp = 0;
 }
 
+// Accesses that must name global memory (a volatile or atomic access through a generic pointer becomes flat_*, which
+// waits on both counters and is not among the hand-off forms measured in MI355X_MICROARCH.md, "Valid forms").
+typedef __attribute__((address_space(1))) uint32_t gu32;
+// agent-scope relaxed atomics lower to global_load / global_store ... sc1: they bypass the per-CU L1 and the
+// non-coherent per-XCD L2 lines, which is what hands data from one CU to another inside a launch
+__device__ __forceinline__ uint32_t ld_sc1(const uint32_t *p) {
+    return __hip_atomic_load((const gu32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(uint32_t *p, uint32_t v) {
+    __hip_atomic_store((gu32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct StackRef {
     uint32_t *lds;   // this lane's column, stride 64
     uint32_t *spill; // this lane's column, stride spill_stride
@@ -569,7 +581,7 @@ __device__ __forceinline__ void stk_push(const StackRef &K, int &sp, uint32_t v)
     if (__builtin_expect(sp < K.lds_entries, 1))
         K.lds[sp * 64] = v;
     else
-        *(volatile uint32_t *)(K.spill + (size_t)(sp - K.lds_entries) * K.spill_stride) = v;
+        *(volatile gu32 *)(K.spill + (size_t)(sp - K.lds_entries) * K.spill_stride) = v;
     sp++;
 }
 __device__ __forceinline__ uint32_t stk_pop(const StackRef &K, int &sp) {
@@ -578,7 +590,7 @@ __device__ __forceinline__ uint32_t stk_pop(const StackRef &K, int &sp) {
     if (__builtin_expect(sp < K.lds_entries, 1))
         v = K.lds[sp * 64];
     else
-        v = *(volatile uint32_t *)(K.spill + (size_t)(sp - K.lds_entries) * K.spill_stride);
+        v = *(volatile gu32 *)(K.spill + (size_t)(sp - K.lds_entries) * K.spill_stride);
     return v;
 }
 
@@ -781,8 +793,10 @@ struct PersistArgs {
 // ns/R samples.  A record has one writer and one reader per round, in turn, so one record per slot is enough; its
 // flag names the round it holds (frame_id * 64 + round).  A lane whose record is not there yet keeps the slot and
 // polls; the writer never waits for anything, so this cannot deadlock.  Who runs which samples cannot change a value.
-// Hand-off between lanes of different CUs / XCDs: state and flag are written and read with system-scope
-// (volatile -> sc0 sc1) accesses, the state drained (vmcnt(0)) before the flag is written.
+// Hand-off between lanes of different CUs / XCDs (MI355X_MICROARCH.md, "Valid forms"): every word of the record and
+// the flag are written by global_store ... sc1 and read by global_load ... sc1 (ld_sc1 / st_sc1), the writing wave
+// drains its stores (s_waitcnt vmcnt(0)) before the flag store, and the reader loads the record only after its own
+// poll of the flag has matched.
 
 #ifdef RT_TRAV_STATS
 #define RT_STAT(I, V) st[I] += (unsigned long long)(V)
@@ -881,19 +895,19 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
         }
         if (ring_on && want_push) { // end of this round's share: publish state, drain, flag
             const uint32_t my_slot = slot_round & 0x3FFFFFFu;
-            volatile uint32_t *sp = P.round_state + (size_t)my_slot * kRingWords;
-            sp[1] = g.v0;
-            sp[2] = g.v1;
-            sp[3] = g.v2;
-            sp[4] = g.v3;
-            sp[5] = g.v4;
-            sp[6] = g.d;
-            sp[7] = __float_as_uint(col.x);
-            sp[8] = __float_as_uint(col.y);
-            sp[9] = __float_as_uint(col.z);
-            sp[10] = (uint32_t)k;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            *(volatile uint32_t *)(P.round_flag + my_slot) = P.frame_id * 64u + (slot_round >> 26) + 1u; // next round's tag
+            uint32_t *sp = P.round_state + (size_t)my_slot * kRingWords;
+            st_sc1(sp + 1, g.v0);
+            st_sc1(sp + 2, g.v1);
+            st_sc1(sp + 3, g.v2);
+            st_sc1(sp + 4, g.v3);
+            st_sc1(sp + 5, g.v4);
+            st_sc1(sp + 6, g.d);
+            st_sc1(sp + 7, __float_as_uint(col.x));
+            st_sc1(sp + 8, __float_as_uint(col.y));
+            st_sc1(sp + 9, __float_as_uint(col.z));
+            st_sc1(sp + 10, (uint32_t)k);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every store of the record has left before the flag goes
+            st_sc1(P.round_flag + my_slot, P.frame_id * 64u + (slot_round >> 26) + 1u); // next round's tag
             has_pixel = false;
         }
         {
@@ -929,16 +943,16 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
             }
             if (ring_on && waiting) { // has the previous round's lane published it yet?
                 const uint32_t my_slot = slot_round & 0x3FFFFFFu;
-                if (*(volatile uint32_t *)(P.round_flag + my_slot) == P.frame_id * 64u + (slot_round >> 26)) {
-                    volatile uint32_t *sp = P.round_state + (size_t)my_slot * kRingWords;
-                    g.v0 = sp[1];
-                    g.v1 = sp[2];
-                    g.v2 = sp[3];
-                    g.v3 = sp[4];
-                    g.v4 = sp[5];
-                    g.d = sp[6];
-                    col = mk(__uint_as_float(sp[7]), __uint_as_float(sp[8]), __uint_as_float(sp[9]));
-                    k = (int)sp[10];
+                if (ld_sc1(P.round_flag + my_slot) == P.frame_id * 64u + (slot_round >> 26)) {
+                    const uint32_t *sp = P.round_state + (size_t)my_slot * kRingWords; // loaded only after the poll matched
+                    g.v0 = ld_sc1(sp + 1);
+                    g.v1 = ld_sc1(sp + 2);
+                    g.v2 = ld_sc1(sp + 3);
+                    g.v3 = ld_sc1(sp + 4);
+                    g.v4 = ld_sc1(sp + 5);
+                    g.d = ld_sc1(sp + 6);
+                    col = mk(__uint_as_float(ld_sc1(sp + 7)), __uint_as_float(ld_sc1(sp + 8)), __uint_as_float(ld_sc1(sp + 9)));
+                    k = (int)ld_sc1(sp + 10);
                     has_pixel = true;
                     need_primary = true;
                     waiting = false;
