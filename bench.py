@@ -5,7 +5,7 @@ A "step" is one frame: one pass of the hot path (camera rays -> BVH traversal ->
 over every pixel this rank owns.  N=1 workload = BASELINE.json configs[2]: synthetic 1 002 528(+2)-triangle
 heightfield, diffuse path tracing, 1920x1080, 64 spp, max depth 8.  For N>1 the frame grows with N at fixed
 aspect and spp (weak scaling: per-GPU pixel count fixed), tiles are interleaved over ranks, and the frame is
-assembled with one RCCL all-reduce (each rank's frame is zero outside its tiles, so the sum is exact).
+assembled on rank 0 with one RCCL reduce (each rank's frame is zero outside its tiles, so the sum is exact).
 
 rays = closest-hit queries (hit() calls, reference pbrt_engine.cu:371), counted on the device.
 Scene, BVH and camera are resident in HBM before the timed region; the frame stays on the device.
@@ -172,8 +172,10 @@ def main():
     def step():
         st = eng.renderDevice(fb.data_ptr())
         if world > 1:
-            dist.all_reduce(fb)  # frame assembly: x + 0 is exact (tiles) / sums of clamped samples (sample shards)
-            if sample_shard:
+            # frame assembly on rank 0 (the host that writes the PPM): x + 0 is exact (tiles) / sums of clamped samples
+            # (sample shards).  A reduce moves half the bytes of an all-reduce over the xGMI ring.
+            dist.reduce(fb, dst=0)
+            if sample_shard and rank == 0:
                 fb.mul_(kk).clamp_(max=1.0)
             torch.cuda.synchronize()  # the next frame's memset runs on the library's own stream
         return st.rays, st.kernel_ms
