@@ -369,6 +369,35 @@ def test_cpp_console_session_equals_the_python_one(oracle, tmp_path):
     eng.close()
 
 
+@pytest.mark.parametrize("n_extra,nx,ny,ns", [(0, 17, 9, 3), (1, 1, 1, 5), (2, 8, 8, 1), (5, 33, 2, 9)])
+def test_tiny_scenes_and_frames(oracle, n_extra, nx, ny, ns):
+    """The small end: one, two, three and six primitives (a one-node tree; leaves that are the whole scene), frames of
+    one pixel / one tile / a sliver, a sample count below the round count -- image and hit ids still the oracle's."""
+    v = np.array([[4, 10, -4], [-4, 10, -4], [-4, 10, 4], [4, 10, 4]], dtype=np.float32)
+    parts = [scenes.make_triangles(v[[3]], v[[2]], v[[1]], 3)]
+    if n_extra >= 1:
+        parts.append(scenes.make_spheres(np.array([[0, 1, 0]], np.float32), [1.0], 7))
+    if n_extra >= 2:
+        g = np.array([[-20, 0, -20], [-20, 0, 20], [20, 0, 20]], dtype=np.float32)
+        parts.append(scenes.make_triangles(g[[0]], g[[1]], g[[2]], 8))
+    if n_extra >= 5:
+        parts.append(scenes.make_spheres(np.array([[2, 0.5, 1], [-2, 0.5, 1], [0, 0.5, 3]], np.float32), [0.5, 0.5, 0.5], 4))
+    tris = np.concatenate(parts)
+    cam = dict(lookfrom=[3, 2.5, 9], lookat=[0, 1, 0], vfov=40.0, dist_to_focus=9.0, aperture=0.1)
+    eng = _engine(tris, nx, ny, ns, 10, cam)
+    fb = eng.render()
+    rays = eng.last_stats.rays
+    ids, ts = eng.tracePrimary()
+    nodes = oracle.build_bvh(tris)
+    assert nodes.tobytes() == eng.getBvhNodes().tobytes()
+    ocam = oracle.camera(cam["lookfrom"], cam["lookat"], 40.0, nx / ny, cam["aperture"], cam["dist_to_focus"])
+    fb_o, cnt = oracle.render(tris, nodes, oracle.material_table(), ocam, nx, ny, ns, 10, mode=0)
+    ids_o, ts_o, _ = oracle.trace_primary(tris, nodes, ocam, nx, ny, mode=0)
+    assert rays == cnt.rays and fb.tobytes() == fb_o.tobytes()
+    assert ids.tobytes() == ids_o.tobytes() and ts.tobytes() == ts_o.tobytes()
+    eng.close()
+
+
 def test_error_behaviour():
     eng = rt_amd.PbrtEngine(32, 32, 1, device=0)
     with pytest.raises(rt_amd.RtError, match="no scene|no camera"):
