@@ -57,7 +57,7 @@ int main(int argc, char **argv) {
     long long rand_calls = rng.calls; // rand() position handed to the next build
     GlCamera cam;
     Mesh *curr = nullptr;
-    bool loop = true;
+    bool loop = true, texture0_set = false;
     std::string line;
     while (loop) {
         std::cout << ">>>:";
@@ -146,6 +146,18 @@ int main(int argc, char **argv) {
                 else if (first == "s") curr->scaleCommand(std::stof(tokens.at(1)));
                 else if (first == "reset") curr->resetAll();
                 else if (first == "radius") std::cout << "radius => " << curr->getAverageRadius() << std::endl;
+                else if (first == "new") { // addXyPlane / addYzPlane / addZxPlane, main.cpp:309-319
+                    const std::string &k = tokens.at(1);
+                    const int kind = (k == "xy" || k == "yx") ? 0 : (k == "yz" || k == "zy") ? 1 : (k == "zx" || k == "xz") ? 2 : -1;
+                    if (kind >= 0) {
+                        registerModel(meshes, plane_mesh(kind));
+                        if (!dump && !texture0_set) { // the planes name texture 0 ("test01.png" in the reference)
+                            const std::vector<unsigned char> t = default_texture();
+                            PbrtEngine::getInstance().setTexture(0, t.data(), 64, 64);
+                            texture0_set = true;
+                        }
+                    }
+                }
             }
         } catch (std::exception &e) {
             std::cout << "Console Error: " << e.what() << std::endl;

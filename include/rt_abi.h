@@ -62,6 +62,7 @@ typedef struct rt_material {
     float param; /* metal: fuzz (already clamped to <= 1); dielectric: ref_idx */
 } rt_material;
 #define RT_MAT_NUM 50 /* MAT_NUM, include/RT/pbrt_engine.h:28 */
+#define RT_TEX_NUM 16 /* textures a context can hold (the reference keeps a vector of texture objects, texture.cpp:45-86) */
 
 typedef struct rt_stats {
     uint64_t rays;        /* closest-hit queries (= hit() calls, pbrt_engine.cu:371) of the last launch */
@@ -90,7 +91,8 @@ int rt_resize(rt_ctx *ctx, int nx, int ny, int ns);
 
 /* m_vecTriangles after __genTrianglesFromScene (pbrt_engine.cu:167-178): n records, the mesh
  * named "light" first.  Copied during the call.  tri[0] must be a triangle (it is the hard-coded
- * light of pbrt_engine.cu:464,502); texIdx must be -1 on every record (textures out of scope). */
+ * light of pbrt_engine.cu:464,502).  A triangle's texIdx is -1 (no texture) or names a texture set with
+ * rt_set_texture before the next render; its u[] / v[] fields are then the vertices' texture coordinates. */
 int rt_set_scene(rt_ctx *ctx, const rt_triangle148 *tris, int n);
 
 /* __genBvhNodes (pbrt_engine.cu:181-202): bit-exact host builder (make_bvh_nodes, :335-368, with
@@ -102,6 +104,12 @@ int rt_build_bvh(rt_ctx *ctx, int64_t rand_calls_before);
 int rt_set_bvh_nodes(rt_ctx *ctx, const rt_bvh_node32 *nodes, int m);
 /* Read back the binary node array (m = 2n-1). cap = capacity of out in nodes. */
 int rt_get_bvh_nodes(rt_ctx *ctx, rt_bvh_node32 *out, int cap, int *m);
+
+/* One texture object (Texture::getTexture -> cudaCreateTextureObject, src/cxx/texture.cpp:45-86): RGBA8 texels, w*h*4
+ * bytes, row 0 first, copied during the call.  Sampled as the reference's descriptor says: normalised coordinates,
+ * wrap addressing, linear filtering, channels as byte/255 (utilities.cu:4-9); only a lambertian triangle with
+ * texIdx != -1 reads it (material.h:100-106).  Image decoding stays with the caller (the reference uses stb). */
+int rt_set_texture(rt_ctx *ctx, int index, const uint8_t *rgba8, int w, int h);
 
 /* material_init + rand_init (pbrt_engine.cu:25-47,597-601) as a host-side table. */
 int rt_default_materials(rt_material out[RT_MAT_NUM]);

@@ -596,6 +596,43 @@ float light_pdf_value(const Scene &sc, V o, V v) {
     return 0.0f;
 }
 
+/* tex2D<float4>(tex, u, v) of getAttenuationFromTexture (src/pbrt/utilities.cu:4-9) on the texture objects that
+ * src/cxx/texture.cpp:74-85 creates: RGBA8 read as normalised float, normalised coordinates, wrap addressing, linear
+ * filtering.  CUDA's filter is hardware (weights in 1.8 fixed point; the rest unspecified): like __cosf it cannot be
+ * reproduced off NVIDIA hardware, so ONE deterministic restatement of the published formula (CUDA C Programming
+ * Guide, "Texture Fetching": xB = x - 0.5, i = floor(xB), alpha = frac(xB) in 8 fractional bits, the four-texel blend)
+ * is shared by the oracle and the product, each implementing it independently.  Parity unpinned. */
+struct OTexture {
+    std::vector<unsigned char> rgba;
+    int w = 0, h = 0;
+};
+static OTexture g_tex[O_TEX_NUM];
+
+static inline float tex_coord(float u, int n, int &i0, int &i1) { /* returns the quantised weight of texel i1 */
+    if (!(std::fabs(u) <= 3.0e38f)) u = 0.0f;      /* NaN / inf: defined as 0 */
+    float x = (u - std::floor(u)) * (float)n;      /* wrap, then scale to texels */
+    float xb = x - 0.5f;
+    float fl = std::floor(xb);
+    float a = xb - fl;
+    a = std::floor(a * 256.0f + 0.5f) / 256.0f;    /* 1.8 fixed point, round to nearest */
+    int i = (int)fl;                                /* -1 .. n-1 */
+    i0 = ((i % n) + n) % n;
+    i1 = (i0 + 1) % n;
+    return a;
+}
+static V tex_fetch(int idx, float u, float v) {
+    const OTexture &T = g_tex[idx];
+    int i0, i1, j0, j1;
+    float a = tex_coord(u, T.w, i0, i1), b = tex_coord(v, T.h, j0, j1);
+    float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    float out[3];
+    for (int c = 0; c < 3; c++) {
+        auto tx = [&](int i, int j) { return (float)T.rgba[4 * ((size_t)j * T.w + i) + c] / 255.0f; };
+        out[c] = ((w00 * tx(i0, j0) + w10 * tx(i1, j0)) + w01 * tx(i0, j1)) + w11 * tx(i1, j1);
+    }
+    return mk(out[0], out[1], out[2]);
+}
+
 /* color(), pbrt_engine.cu:459-566 */
 V path_color(const Scene &sc, const o_mat *mats, int max_depth, int mode, const Ray &primary, Rng &g, o_counts &cnt) {
     Ray cur = primary;
@@ -605,9 +642,9 @@ V path_color(const Scene &sc, const o_mat *mats, int max_depth, int mode, const 
         if (scene_hit(sc, mode, cur, 0.001f, FLT_MAX, rec, cnt)) {
             const o_mat &m = mats[rec.mat];
             V alb = ld(m.albedo);
-            if (m.kind == O_LAMBERTIAN) { /* material.h:95-116; texIdx must be -1 (textures out of scope) */
+            if (m.kind == O_LAMBERTIAN) { /* material.h:95-116 */
                 Onb b = onb_from_w(rec.n);
-                V atten = alb;
+                V atten = rec.tex == -1 ? alb : tex_fetch(rec.tex, rec.u, rec.v); /* :100-106 */
                 (void)rng_uniform(g); /* pbrt_engine.cu:505, thres = 1 */
                 Ray sc_ray;
                 sc_ray.o = rec.p;
@@ -792,6 +829,18 @@ void o_material_table(o_mat out[50]) { /* material_init, pbrt_engine.cu:25-47 */
         float f = rng_uniform(g) / 50;
         set(i, O_METAL, r, gg, b, fuzz(f));
     }
+}
+
+int o_set_texture(int idx, const unsigned char *rgba, int w, int h) {
+    if (idx < 0 || idx >= O_TEX_NUM || w <= 0 || h <= 0 || !rgba) return 1;
+    g_tex[idx].rgba.assign(rgba, rgba + (size_t)4 * w * h);
+    g_tex[idx].w = w;
+    g_tex[idx].h = h;
+    return 0;
+}
+void o_tex_fetch(int idx, float u, float v, float out[3]) {
+    V c = tex_fetch(idx, u, v);
+    st(out, c);
 }
 
 int o_build_bvh(const o_tri148 *tris, int n, o_node32 *out) { return o_build_bvh_after(tris, n, 0, out); }

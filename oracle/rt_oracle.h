@@ -89,6 +89,12 @@ void o_material_table(o_mat out[50]);
 
 /* -- make_bvh_nodes, pbrt_engine.cu:335-368; srand(1) (= glibc default state) first.
  *    out must hold 2n-1 nodes.  returns node count. -- */
+/* -- textures (lambertian albedo when a triangle's texIdx != -1; material.h:100-106, utilities.cu:4-9): RGBA8,
+ *    w*h texels, row 0 first.  A process-wide table: the oracle is a test tool. -- */
+#define O_TEX_NUM 16
+int o_set_texture(int idx, const unsigned char *rgba, int w, int h);
+void o_tex_fetch(int idx, float u, float v, float out[3]);
+
 int o_build_bvh(const o_tri148 *tris, int n, o_node32 *out);
 /* same, with rand() advanced by rand_calls_before draws first (the reference shares the unseeded rand() between
  * scene setup, main.cpp:449-474, and every build of a session) */

@@ -96,6 +96,7 @@ class Console:
         self.loop = True
         self.last_frame = None
         self.last_triangles = None
+        self._texture0_set = False
 
     # ---------------------------------------------------------------- render
     def _render(self, build_scene: bool, out):
@@ -226,8 +227,14 @@ class Console:
             curr.reset_all()
         elif first == "radius":
             print(f"radius => {_fmt(curr.average_radius())}", file=out)
-        elif first == "new":
-            raise RuntimeError("new xy|yz|zx adds a textured plane: textures are outside the trace-loop scope")
+        elif first == "new":  # addXyPlane / addYzPlane / addZxPlane, main.cpp:309-319 (needs a selected model, as there)
+            kind = {"xy": "xy", "yx": "xy", "yz": "yz", "zy": "yz", "zx": "zx", "xz": "zx"}.get(tokens[1])
+            if kind:
+                m = sg.plane_mesh(kind)
+                self.meshes.setdefault(m.name, m)
+                if not self._texture0_set:  # the planes name texture 0 ("test01.png" in the reference)
+                    self.engine.setTexture(0, sg.default_texture())
+                    self._texture0_set = True
         elif first in ("ambient", "specular", "diffuse"):
             [float(t) for t in tokens[1:4]]  # GL shading colours: parsed as the reference does, unused by the trace loop
         # hide / show / log position / viewport: window-side state only

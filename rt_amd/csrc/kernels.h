@@ -15,6 +15,8 @@ struct KernelScene {
     const float4 *prims; // DevPrim[], 3 float4 each, DFS leaf order
     const float4 *shade; // DevShade[], 1 float4 each
     const DevMat *mats;  // RT_MAT_NUM entries
+    const float4 *uv;    // DevUV[], 2 float4 each, or nullptr: no triangle of the scene is textured
+    const DevTex *tex;   // RT_TEX_NUM entries (only read when uv != nullptr)
 };
 
 struct KernelFrame {

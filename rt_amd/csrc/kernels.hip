@@ -295,10 +295,65 @@ __device__ __forceinline__ float schlick_ref(float cosine, float ref_idx) { // m
     return r0 + (1.0f - r0) * pow5_sh(1.0f - cosine);
 }
 
+// tex2D<float4>(tex, u, v) of getAttenuationFromTexture (src/pbrt/utilities.cu:4-9): RGBA8 as normalised float,
+// normalised coordinates, wrap addressing, linear filtering (src/cxx/texture.cpp:74-85).  CUDA's filter is hardware;
+// this is the shared deterministic restatement of its published formula, written independently of
+// the oracle's: weights in 8 fractional bits, float blend without FMA in a fixed order.
+__device__ __forceinline__ float tex_coord(float u, int n, int &i0, int &i1) {
+    if (!(__builtin_fabsf(u) <= 3.0e38f)) u = 0.0f;
+    const float x = (u - __builtin_floorf(u)) * (float)n;
+    const float xb = x - 0.5f;
+    const float fl = __builtin_floorf(xb);
+    float a = xb - fl;
+    a = __builtin_floorf(a * 256.0f + 0.5f) / 256.0f;
+    const int i = (int)fl;
+    i0 = ((i % n) + n) % n;
+    i1 = (i0 + 1) % n;
+    return a;
+}
+__device__ __forceinline__ V3 tex_fetch(const DevTex &T, float u, float v) {
+    int i0, i1, j0, j1;
+    const float a = tex_coord(u, T.w, i0, i1), b = tex_coord(v, T.h, j0, j1);
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    const uchar4 *tx = reinterpret_cast<const uchar4 *>(T.texels);
+    const uchar4 t00 = tx[(size_t)j0 * T.w + i0], t10 = tx[(size_t)j0 * T.w + i1];
+    const uchar4 t01 = tx[(size_t)j1 * T.w + i0], t11 = tx[(size_t)j1 * T.w + i1];
+#define RT_TEXC(C) (((w00 * ((float)t00.C / 255.0f) + w10 * ((float)t10.C / 255.0f)) + w01 * ((float)t01.C / 255.0f)) + w11 * ((float)t11.C / 255.0f))
+    const V3 c = mk(RT_TEXC(x), RT_TEXC(y), RT_TEXC(z));
+#undef RT_TEXC
+    return c;
+}
+
+// lambertian::scatter's attenuation for a textured triangle (material.h:100-106): the hit record's (u, v) are the
+// barycentric blend of the vertices' texture coordinates (setUV, triangle.h:113-118, with 1.0 - x - y in double).
+// The barycentrics are recomputed here with the arithmetic of prim_test: same inputs, same bits.
+__device__ __forceinline__ V3 textured_albedo(const KernelScene &S, int rank, const Ray &r, V3 alb) {
+    const float4 q0 = S.uv[2 * (size_t)rank], q1 = S.uv[2 * (size_t)rank + 1];
+    const int tex = __float_as_int(q1.z);
+    if (tex == -1) return alb;
+    const float4 *p = S.prims + 3 * (size_t)rank;
+    const float4 A = p[0], B = p[1], C = p[2];
+    const V3 v0 = mk(A.x, A.y, A.z), e1 = mk(A.w, B.x, B.y), e2 = mk(B.z, B.w, C.x);
+    const V3 tvec = vsub(r.o, v0);
+    const V3 pvec = vcross(r.d, e2);
+    float det = vdot(e1, pvec);
+    det = 1.0f / det;
+    const float x = vdot(tvec, pvec) * det;
+    const V3 qvec = vcross(tvec, e1);
+    const float y = vdot(r.d, qvec) * det;
+    const float z = (float)(1.0 - (double)x - (double)y);
+    const float u = z * q0.x + x * q0.y + y * q0.z;
+    const float v = z * q0.w + x * q1.x + y * q1.y;
+    return tex_fetch(S.tex[tex], u, v);
+}
+
 // One bounce of color() (pbrt_engine.cu:467-560) after hit() has returned.
 // Returns true if the path continues with `cur` replaced; false if the sample is finished, in which
 // case `thr` is the sample's value BEFORE the per-sample clamp, and `clamp` says whether to apply it
 // (the pdf < 1e-6 exit at :519-521 returns black unclamped).
+// TEX: compiled with the texture path (taken when the scene has texture coordinates).  The product kernel keeps an
+// instance without it: inlined, the path costs 40 spilled registers at 80 VGPRs even when no triangle is textured.
+template <bool TEX>
 __device__ __forceinline__ bool shade_bounce(const KernelScene &S, const Hit &h, Ray &cur, V3 &thr, Rng &g, bool &clamp) {
     clamp = true;
     if (h.rank == RT_NO_HIT) { // sky, :554-558
@@ -325,6 +380,8 @@ __device__ __forceinline__ bool shade_bounce(const KernelScene &S, const Hit &h,
     const DevMat m = S.mats[mat_id];
     const V3 alb = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
     if (m.kind == RT_MAT_LAMBERTIAN) { // material.h:95-116 + pbrt_engine.cu:500-525
+        V3 atten = alb;
+        if (TEX && S.uv != nullptr && shape == 0) atten = textured_albedo(S, h.rank, cur, alb);
         Onb b = onb_from_w(n);
         (void)rng_uniform(g); // :505
         V3 dir = cosine_generate(b, g);
@@ -339,7 +396,7 @@ __device__ __forceinline__ bool shade_bounce(const KernelScene &S, const Hit &h,
         float cosine = vdot(n, vunit(dir)); // lambertian::scatter_pdf
         if ((double)cosine < 0.0) cosine = 0.0f;
         float spdf = (float)((double)cosine / 3.1415926);
-        thr = vmul(thr, vdiv(vscl(spdf, alb), pdf));
+        thr = vmul(thr, vdiv(vscl(spdf, atten), pdf));
         cur.o = p;
         cur.d = dir;
         return true;
@@ -490,7 +547,7 @@ __global__ void __launch_bounds__(64) k_render(KernelScene S, KernelFrame F, flo
             Hit h = closest_hit(S.nodes, S.prims, cur, s_stack + threadIdx.x);
             nr++;
             bool clamp;
-            bool go_on = shade_bounce(S, h, cur, thr, g, clamp);
+            bool go_on = shade_bounce<true>(S, h, cur, thr, g, clamp);
             bounce++;
             if (!go_on || bounce >= F.max_depth) { // ITER_NUM exhausted: falls to RETURN_COLOR with the throughput
                 if (clamp) clip_color(thr);       // per-SAMPLE clamp, :564
@@ -809,7 +866,7 @@ struct PersistArgs {
 // traversing nodes; the expensive primitive test runs only when `leaf_batch` lanes have one pending (or no
 // lane has node work), so it executes with many lanes instead of the one or two that happen to sit on a leaf.
 // OCC: waves per SIMD the register allocation is held to (__launch_bounds__' second argument).
-template <int MODE, int FMT, int SPEC, int OCC>
+template <int MODE, int FMT, int SPEC, int OCC, bool TEX>
 __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFrame F, PersistArgs P, float *fb, int32_t *ids,
                                                    float *ts) {
     const uint32_t lane = threadIdx.x;
@@ -869,7 +926,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                 has_pixel = false;
             } else {
                 bool clamp;
-                bool go_on = shade_bounce(S, h, cur, thr, g, clamp);
+                bool go_on = shade_bounce<TEX>(S, h, cur, thr, g, clamp);
                 bounce++;
                 if (!go_on || bounce >= F.max_depth) {
                     if (clamp) clip_color(thr);
@@ -1142,7 +1199,7 @@ __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, 
             h.t = wt;
             h.rank = wrank;
             bool clamp;
-            const bool go_on = shade_bounce(S, h, wr, pw.thr, pw.g, clamp);
+            const bool go_on = shade_bounce<true>(S, h, wr, pw.thr, pw.g, clamp);
             pw.bounce++;
             w_status = RT_W_READY;
             if (!go_on || pw.bounce >= F.max_depth) {
@@ -1341,8 +1398,19 @@ hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &
             hipLaunchKernelGGL((k_dual<1, 4>), grid, block, lds, stream, S, F, P, D, fb);
         return hipGetLastError();
     }
+    if (mode == 0 && S.uv != nullptr) { // textured scene: the instances with the texture path, 128 VGPRs (4 waves/SIMD)
+        if (L.node_format == 0 && !L.speculative)
+            hipLaunchKernelGGL((k_persistent<0, 0, 0, 4, true>), grid, block, lds, stream, S, F, P, fb, ids, ts);
+        else if (L.node_format == 0)
+            hipLaunchKernelGGL((k_persistent<0, 0, 1, 4, true>), grid, block, lds, stream, S, F, P, fb, ids, ts);
+        else if (!L.speculative)
+            hipLaunchKernelGGL((k_persistent<0, 1, 0, 4, true>), grid, block, lds, stream, S, F, P, fb, ids, ts);
+        else
+            hipLaunchKernelGGL((k_persistent<0, 1, 1, 4, true>), grid, block, lds, stream, S, F, P, fb, ids, ts);
+        return hipGetLastError();
+    }
 #define RT_LAUNCH(M, Fm, Sp, Oc)                                                                                       \
-    hipLaunchKernelGGL((k_persistent<M, Fm, Sp, Oc>), grid, block, lds, stream, S, F, P, fb, ids, ts)
+    hipLaunchKernelGGL((k_persistent<M, Fm, Sp, Oc, false>), grid, block, lds, stream, S, F, P, fb, ids, ts)
 #define RT_LAUNCH_OCC(M, Sp)                                                                                           \
     if (L.occupancy >= 8)                                                                                              \
         RT_LAUNCH(M, 1, Sp, 8);                                                                                        \

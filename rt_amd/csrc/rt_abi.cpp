@@ -37,6 +37,12 @@ struct rt_ctx {
     uint32_t frame_id = 0;
     unsigned long long seed_salt = 0;
     int raw_sum = 0;
+    // textures (lambertian albedo of triangles with texIdx != -1)
+    void *d_uv = nullptr;
+    DevTex *d_tex = nullptr;               // RT_TEX_NUM descriptors
+    unsigned char *d_texels[RT_TEX_NUM] = {}; // device copies
+    int tex_w[RT_TEX_NUM] = {}, tex_h[RT_TEX_NUM] = {};
+    bool tex_dirty = true;
     int refill_threshold = 24, waves_per_cu = 24, lds_stack = 16, node_format = 1, leaf_batch = 16, occupancy = 6, topology = 1;
     int n_cus = 256;
     unsigned int *d_bands = nullptr;
@@ -131,7 +137,8 @@ void free_scene(rt_ctx *c) {
     if (c->d_qnodes) (void)hipFree(c->d_qnodes);
     if (c->d_prims) (void)hipFree(c->d_prims);
     if (c->d_shade) (void)hipFree(c->d_shade);
-    c->d_nodes = c->d_qnodes = c->d_prims = c->d_shade = nullptr;
+    if (c->d_uv) (void)hipFree(c->d_uv);
+    c->d_nodes = c->d_qnodes = c->d_prims = c->d_shade = c->d_uv = nullptr;
     c->scene_on_device = false;
 }
 
@@ -168,8 +175,33 @@ int upload_scene(rt_ctx *c) {
     HIPCHK(c, hipMemcpyAsync(c->d_nodes, c->wide.nodes.data(), nb, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_prims, c->wide.prims.data(), pb, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_shade, c->wide.shade.data(), sb, hipMemcpyHostToDevice, c->stream));
+    if (!c->wide.uv.empty()) {
+        const size_t ub = c->wide.uv.size() * sizeof(DevUV);
+        HIPCHK(c, hipMalloc(&c->d_uv, ub));
+        HIPCHK(c, hipMemcpyAsync(c->d_uv, c->wide.uv.data(), ub, hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->scene_on_device = true;
+    return RT_OK;
+}
+
+// every texture a triangle names must have been set; the descriptor table is refreshed when a texture changed
+int upload_textures(rt_ctx *c) {
+    if (c->wide.uv.empty()) return RT_OK;
+    for (const DevUV &q : c->wide.uv)
+        if (q.tex != -1 && !c->d_texels[q.tex])
+            return fail(c, RT_E_ARG, "a triangle names texture " + std::to_string(q.tex) + ", which was never set (rt_set_texture)");
+    if (!c->tex_dirty) return RT_OK;
+    DevTex tmp[RT_TEX_NUM];
+    for (int i = 0; i < RT_TEX_NUM; i++) {
+        tmp[i].texels = c->d_texels[i];
+        tmp[i].w = c->tex_w[i];
+        tmp[i].h = c->tex_h[i];
+    }
+    if (!c->d_tex) HIPCHK(c, hipMalloc((void **)&c->d_tex, sizeof(tmp)));
+    HIPCHK(c, hipMemcpyAsync(c->d_tex, tmp, sizeof(tmp), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->tex_dirty = false;
     return RT_OK;
 }
 
@@ -205,6 +237,8 @@ int ready_to_trace(rt_ctx *c) {
         int rc = upload_scene(c);
         if (rc) return rc;
     }
+    int rc = upload_textures(c);
+    if (rc) return rc;
     return upload_mats(c);
 }
 
@@ -233,6 +267,8 @@ KernelScene scene_of(rt_ctx *c) {
     S.prims = (const float4 *)c->d_prims;
     S.shade = (const float4 *)c->d_shade;
     S.mats = c->d_mats;
+    S.uv = (const float4 *)c->d_uv;
+    S.tex = c->d_tex;
     return S;
 }
 
@@ -250,7 +286,9 @@ void fill_stats(rt_ctx *c, rt_stats *st, uint64_t rays, float ms, double total_m
 // kernel variant 1: zero the band counters, size the spill area, fill the launch record
 int prepare_persistent(rt_ctx *c, PersistLaunch &L, bool render) {
     // primary rays are short and coherent: 16 waves per CU measured 20 % faster than 24 (2.4 vs 2.0 Grays/s at 1080p)
-    L.grid_waves = c->n_cus * (render ? c->waves_per_cu : std::min(c->waves_per_cu, 16));
+    // textured scenes run the 128-VGPR instances (4 waves/SIMD): no point in launching more waves than are resident
+    const bool four_per_simd = !render || !c->wide.uv.empty();
+    L.grid_waves = c->n_cus * (four_per_simd ? std::min(c->waves_per_cu, 16) : c->waves_per_cu);
     L.lds_entries = c->lds_stack < c->wide.stack_entries ? c->lds_stack : c->wide.stack_entries;
     L.threshold = c->refill_threshold;
     L.node_format = c->node_format;
@@ -312,6 +350,22 @@ double now_ms() {
 extern "C" {
 
 int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_set_texture(rt_ctx *c, int index, const uint8_t *rgba8, int w, int h) {
+    if (!c) return RT_E_ARG;
+    if (index < 0 || index >= RT_TEX_NUM) return fail(c, RT_E_ARG, "texture index out of range");
+    if (!rgba8 || w <= 0 || h <= 0 || w > 32768 || h > 32768) return fail(c, RT_E_ARG, "texture must be 1..32768 texels per side");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->d_texels[index]) (void)hipFree(c->d_texels[index]);
+    c->d_texels[index] = nullptr;
+    const size_t bytes = (size_t)4 * w * h;
+    HIPCHK(c, hipMalloc((void **)&c->d_texels[index], bytes));
+    HIPCHK(c, hipMemcpy(c->d_texels[index], rgba8, bytes, hipMemcpyHostToDevice));
+    c->tex_w[index] = w;
+    c->tex_h[index] = h;
+    c->tex_dirty = true;
+    return RT_OK;
+}
 
 int rt_default_materials(rt_material out[RT_MAT_NUM]) {
     if (!out) return RT_E_ARG;
@@ -388,6 +442,9 @@ int rt_destroy(rt_ctx *c) {
     if (c->d_mats) (void)hipFree(c->d_mats);
     if (c->d_counter) (void)hipFree(c->d_counter);
     if (c->d_bands) (void)hipFree(c->d_bands);
+    if (c->d_tex) (void)hipFree(c->d_tex);
+    for (int i = 0; i < RT_TEX_NUM; i++)
+        if (c->d_texels[i]) (void)hipFree(c->d_texels[i]);
     if (c->d_ring_state) (void)hipFree(c->d_ring_state);
     if (c->d_ring_flag) (void)hipFree(c->d_ring_flag);
     if (c->d_spill) (void)hipFree(c->d_spill);
@@ -422,8 +479,8 @@ int rt_set_scene(rt_ctx *c, const rt_triangle148 *tris, int n) {
     for (int i = 0; i < n; i++) {
         if (tris[i].shapeType != 0 && tris[i].shapeType != 1)
             return fail(c, RT_E_UNSUPPORTED, "shapeType must be 0 (triangle) or 1 (sphere)");
-        if (tris[i].shapeType == 0 && tris[i].texIdx != -1)
-            return fail(c, RT_E_UNSUPPORTED, "texIdx must be -1: the texture path is out of scope");
+        if (tris[i].shapeType == 0 && (tris[i].texIdx < -1 || tris[i].texIdx >= RT_TEX_NUM))
+            return fail(c, RT_E_ARG, "texIdx must be -1 (no texture) or an index below RT_TEX_NUM");
         if (tris[i].matType < 0 || tris[i].matType >= RT_MAT_NUM) return fail(c, RT_E_ARG, "matType out of range");
     }
     HIPCHK(c, hipSetDevice(c->device));

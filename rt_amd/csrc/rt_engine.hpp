@@ -60,6 +60,10 @@ class PbrtEngine {
     void setCamera(const float lookfrom[3], const float lookat[3], float zoom, float dist_to_focus, float aperture) {
         check(rt_set_camera(ctx, lookfrom, lookat, zoom, dist_to_focus, aperture), "rt_set_camera");
     }
+    // one texture object (Texture::getTexture, src/cxx/texture.cpp:45-86): RGBA8, row 0 first
+    void setTexture(int index, const unsigned char *rgba8, int w, int h) {
+        check(rt_set_texture(ctx, index, rgba8, w, h), "rt_set_texture");
+    }
     void setMaxDepth(int d) { check(rt_set_option(ctx, RT_OPT_MAX_DEPTH, d), "rt_set_option"); }
 
     // renderScene + __renderScene + join (pbrt_engine.cu:89-157); synchronous, as main.cpp:217-219 makes it

@@ -83,7 +83,10 @@ inline Vec3 apply(const Mat4 &m, Vec3 p) {
 }
 
 // Triangle(v0, v1, v2, matType, texIdx) -> setTriangle (include/RT/triangle.h:90-111)
-inline rt_triangle148 make_triangle(Vec3 a, Vec3 b, Vec3 c, int mat, int tex) {
+struct Vec2 {
+    float x = 0, y = 0;
+};
+inline rt_triangle148 make_triangle(Vec3 a, Vec3 b, Vec3 c, int mat, int tex, Vec2 ta = {}, Vec2 tb = {}, Vec2 tc = {}) {
     rt_triangle148 t;
     std::memset(&t, 0, sizeof(t));
     const float va[3] = {a.x, a.y, a.z}, vb[3] = {b.x, b.y, b.z}, vc[3] = {c.x, c.y, c.z};
@@ -104,6 +107,12 @@ inline rt_triangle148 make_triangle(Vec3 a, Vec3 b, Vec3 c, int mat, int tex) {
     t.matType = mat;
     t.shapeType = 0;
     t.texIdx = tex;
+    t.u[0] = ta.x; // Triangle(..., vec3(uv1[0], uv2[0], uv3[0]), vec3(uv1[1], uv2[1], uv3[1])), mesh.cpp:148-149
+    t.u[1] = tb.x;
+    t.u[2] = tc.x;
+    t.v[0] = ta.y;
+    t.v[1] = tb.y;
+    t.v[2] = tc.y;
     return t;
 }
 // Triangle(centre, radius, matType) (triangle.h:95-100)
@@ -123,8 +132,10 @@ inline rt_triangle148 make_sphere(Vec3 c, float r, int mat) {
 
 class Mesh {
   public:
-    Mesh(std::string name, std::vector<Vec3> v, std::vector<unsigned> idx, int mat = 0)
-        : m_strName(std::move(name)), vertices(std::move(v)), indices(std::move(idx)), matType(mat) {}
+    Mesh(std::string name, std::vector<Vec3> v, std::vector<unsigned> idx, int mat = 0, std::vector<Vec2> tc = {})
+        : m_strName(std::move(name)), vertices(std::move(v)), indices(std::move(idx)), texcoords(std::move(tc)), matType(mat) {
+        texcoords.resize(vertices.size()); // Vertex::TexCoords; zero where the reference's loader would supply them
+    }
     virtual ~Mesh() = default;
 
     // console commands, mesh.h:293-364
@@ -182,12 +193,14 @@ class Mesh {
         }
         for (size_t i = 0; i + 2 < indices.size(); i += 3)
             out.push_back(make_triangle(apply(model, vertices[indices[i]]), apply(model, vertices[indices[i + 1]]),
-                                        apply(model, vertices[indices[i + 2]]), getMatType(), texIdx));
+                                        apply(model, vertices[indices[i + 2]]), getMatType(), texIdx, texcoords[indices[i]],
+                                        texcoords[indices[i + 1]], texcoords[indices[i + 2]]));
     }
 
     std::string m_strName;
     std::vector<Vec3> vertices;
     std::vector<unsigned> indices;
+    std::vector<Vec2> texcoords;
     int matType = 0, texIdx = -1;
     bool m_bIsSphere = false;
     float m_fTranslationX = 0, m_fTranslationY = 0, m_fTranslationZ = 0;
@@ -264,9 +277,44 @@ inline std::vector<rt_triangle148> gather(const Collection &c) {
 }
 
 // make_a_cornell_light (include/RT/MeshFactory.h:423-429 -> 29-74): flipped quad at y = 10, material 3
+inline std::vector<Vec2> quad_uv(bool flip) { // TexCoords of the four corners of every factory quad
+    return flip ? std::vector<Vec2>{{1, 1}, {1, 0}, {0, 0}, {0, 1}} : std::vector<Vec2>{{0, 1}, {0, 0}, {1, 0}, {1, 1}};
+}
 inline MESH_PTR light_mesh() {
     return std::make_shared<Mesh>("light", std::vector<Vec3>{{4, 10, -4}, {-4, 10, -4}, {-4, 10, 4}, {4, 10, 4}},
-                                  std::vector<unsigned>{3, 2, 1, 3, 1, 0}, 3);
+                                  std::vector<unsigned>{3, 2, 1, 3, 1, 0}, 3, quad_uv(true));
+}
+// make_a_{xy,yz,zx}_plane(w, h, flip) as addXyPlane / addYzPlane / addZxPlane register it (MeshFactory.h:76-126,
+// 181-230, 285-335; main.cpp:43-66): material LAMBERTIAN = 10 (main.cpp:20), texture index 0.  kind: 0 xy, 1 yz, 2 zx
+inline MESH_PTR plane_mesh(int kind, float w = 1.0f, float h = 1.0f, int texIdx = 0, bool flip = false) {
+    const float hw = w / 2, hh = h / 2;
+    std::vector<Vec3> v;
+    if (kind == 0)
+        v = {{-hw, hh, 0}, {-hw, -hh, 0}, {hw, -hh, 0}, {hw, hh, 0}};
+    else if (kind == 1)
+        v = {{0, hh, -hw}, {0, -hh, -hw}, {0, -hh, hw}, {0, hh, hw}};
+    else
+        v = {{hh, 0, -hw}, {-hh, 0, -hw}, {-hh, 0, hw}, {hh, 0, hw}};
+    const char *names[3] = {"xy", "yz", "zx"};
+    auto m = std::make_shared<Mesh>(std::string(names[kind]) + (flip ? "_flip" : ""), v,
+                                    flip ? std::vector<unsigned>{3, 2, 1, 3, 1, 0} : std::vector<unsigned>{0, 1, 2, 0, 2, 3}, 10,
+                                    quad_uv(flip));
+    m->texIdx = texIdx;
+    return m;
+}
+// stand-in for test01.png (absent): an n x n RGBA8 checkerboard of 8 x 8 squares, integers only
+inline std::vector<unsigned char> default_texture(int n = 64) {
+    std::vector<unsigned char> t((size_t)n * n * 4);
+    for (int j = 0; j < n; j++)
+        for (int i = 0; i < n; i++) {
+            const bool on = ((j * 8 / n + i * 8 / n) % 2) == 0;
+            unsigned char *p = &t[4 * ((size_t)j * n + i)];
+            p[0] = on ? 230 : 40;
+            p[1] = on ? 230 : 60;
+            p[2] = on ? 220 : 160;
+            p[3] = 255;
+        }
+    return t;
 }
 // stand-in for models/cube.obj (absent): the canonical +-1 cube, 12 triangles
 inline MESH_PTR unit_cube_mesh(const std::string &name) {

@@ -60,6 +60,21 @@ struct DevShade {
     int32_t mat;
 };
 
+// ---- texture coordinates of a triangle, only allocated when the scene has a textured triangle: 32 bytes, same order.
+//      u[k], v[k] = texture coordinate of vertex k (Triangle::u / ::v, include/RT/triangle.h:345-354) ----
+struct DevUV {
+    float u[3];
+    float v0;
+    float v12[2];
+    int32_t tex; // texIdx; -1 = none
+    int32_t pad;
+};
+// one texture: RGBA8 texels in device memory, row 0 first
+struct DevTex {
+    const unsigned char *texels;
+    int32_t w, h;
+};
+
 // ---- material, camera: small PODs kept in kernel-argument / constant space ----
 struct DevMat {
     int32_t kind;

@@ -161,6 +161,23 @@ bool build_wide_bvh(const rt_triangle148 *tris, int n, const rt_bvh_node32 *node
         s.mat = t.matType;
     }
 
+    // ---- texture coordinates, only for scenes that use them ----
+    bool textured = false;
+    for (int i = 0; i < n && !textured; i++) textured = tris[i].shapeType == 0 && tris[i].texIdx != -1;
+    if (textured) {
+        out.uv.resize(n);
+        for (int r = 0; r < n; r++) {
+            const rt_triangle148 &t = tris[order[r]];
+            DevUV &q = out.uv[r];
+            for (int k = 0; k < 3; k++) q.u[k] = t.u[k];
+            q.v0 = t.v[0];
+            q.v12[0] = t.v[1];
+            q.v12[1] = t.v[2];
+            q.tex = t.shapeType == 0 ? t.texIdx : -1; // a sphere's hit record always says -1 (triangle.h:207)
+            q.pad = 0;
+        }
+    }
+
     // ---- pad for re-fitted boxes: 2^-17 of the largest |coordinate| of the scene ----
     float extent = 0.0f;
     {

@@ -16,6 +16,7 @@ struct WideBvh {
     std::vector<QuantNode> qnodes; // the same nodes, quantized (rt_types.h); same indices
     std::vector<DevPrim> prims;  // DFS leaf order of the binary tree
     std::vector<DevShade> shade; // same order
+    std::vector<DevUV> uv;       // same order; empty unless some triangle has texIdx != -1
     int depth = 0;               // wide levels below the root node (root = 1)
     int stack_entries = 0;       // worst-case traversal stack entries per ray
     float pad = 0.0f;            // box pad actually applied (box_mode 0)

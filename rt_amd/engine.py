@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     "rt_set_bvh_nodes", "rt_get_bvh_nodes", "rt_default_materials", "rt_set_materials", "rt_set_camera",
     "rt_set_option", "rt_get_option", "rt_render", "rt_render_device", "rt_trace_primary", "rt_trace_rays",
     "rt_write_ppm", "rt_test_glibc_rand", "rt_test_introsort", "rt_test_build_bvh", "rt_test_wide_layout", "rt_test_tile_owner",
-    "rt_test_trav_stats", "rt_test_sincosf",
+    "rt_test_trav_stats", "rt_test_sincosf", "rt_set_texture",
 ]
 
 
@@ -91,6 +91,7 @@ def load_library(path: str = LIB_PATH):
     lib.rt_default_materials.argtypes = [vp]
     lib.rt_set_materials.argtypes = [vp, vp, C.c_int]
     lib.rt_set_camera.argtypes = [vp, fp, fp, C.c_float, C.c_float, C.c_float]
+    lib.rt_set_texture.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int]
     lib.rt_set_option.argtypes = [vp, C.c_int, C.c_int64]
     lib.rt_get_option.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
     lib.rt_render.argtypes = [vp, vp, C.POINTER(RtStats)]
@@ -274,6 +275,12 @@ class PbrtEngine:
     def setMaterials(self, mats: np.ndarray):
         mats = np.ascontiguousarray(mats, dtype=MAT_DTYPE)
         self._check(self._lib.rt_set_materials(self._h, _ptr(mats), int(mats.shape[0])), "rt_set_materials")
+
+    def setTexture(self, index: int, rgba8: np.ndarray):
+        """One RGBA8 texture, shape (h, w, 4) uint8, row 0 first (Texture::getTexture, src/cxx/texture.cpp:45-86)."""
+        t = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        assert t.ndim == 3 and t.shape[2] == 4
+        self._check(self._lib.rt_set_texture(self._h, index, _ptr(t), t.shape[1], t.shape[0]), "rt_set_texture")
 
     def setCamera(self, lookfrom, lookat, vfov: float = 40.0, dist_to_focus: float = 10.0, aperture: float = 0.0):
         a = (C.c_float * 3)(*[float(x) for x in lookfrom])

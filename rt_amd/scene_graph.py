@@ -124,9 +124,12 @@ def _apply(m: np.ndarray, p: np.ndarray) -> np.ndarray:
 class Mesh:
     """GL-free restatement of the fields of ``Mesh`` that reach the kernel."""
 
-    def __init__(self, name: str, vertices, indices, mat_type: int = 0, tex_idx: int = -1):
+    def __init__(self, name: str, vertices, indices, mat_type: int = 0, tex_idx: int = -1, texcoords=None):
         self.name = name
         self.vertices = np.asarray(vertices, dtype=F).reshape(-1, 3)
+        # Vertex::TexCoords; zero where the reference's loader would have supplied them (assimp, absent)
+        self.texcoords = (np.zeros((self.vertices.shape[0], 2), dtype=F) if texcoords is None
+                          else np.asarray(texcoords, dtype=F).reshape(-1, 2))
         self.indices = np.asarray(indices, dtype=np.int64).reshape(-1)
         self.mat_type = mat_type
         self.tex_idx = tex_idx
@@ -204,7 +207,8 @@ class Mesh:
             return scenes.make_spheres(centre, [self.average_radius()], self.get_mat_type())
         tri = self.indices.reshape(-1, 3)
         w = _apply(model, self.vertices)
-        return scenes.make_triangles(w[tri[:, 0]], w[tri[:, 1]], w[tri[:, 2]], self.get_mat_type(), self.tex_idx)
+        uv = np.stack([self.texcoords[tri[:, 0]], self.texcoords[tri[:, 1]], self.texcoords[tri[:, 2]]], axis=1)
+        return scenes.make_triangles(w[tri[:, 0]], w[tri[:, 1]], w[tri[:, 2]], self.get_mat_type(), self.tex_idx, uv=uv)
 
 
 class FlyWeight(Mesh):
@@ -306,7 +310,41 @@ def gather(meshes) -> np.ndarray:
 def light_mesh() -> Mesh:
     """make_a_cornell_light (include/RT/MeshFactory.h:423-429 -> 29-74): flipped quad at y = 10, material 3."""
     v = [[4, 10, -4], [-4, 10, -4], [-4, 10, 4], [4, 10, 4]]
-    return Mesh("light", v, [3, 2, 1, 3, 1, 0], mat_type=3)
+    return Mesh("light", v, [3, 2, 1, 3, 1, 0], mat_type=3, texcoords=_FLIP_UV)
+
+
+_UV = [[0, 1], [0, 0], [1, 0], [1, 1]]       # TexCoords of the four corners of every factory quad
+_FLIP_UV = [[1, 1], [1, 0], [0, 0], [0, 1]]  # ... of its flipped variant
+
+
+def plane_mesh(kind: str, w: float = 1.0, h: float = 1.0, tex_idx: int = 0, flip: bool = False) -> Mesh:
+    """make_a_{xy,yz,zx}_plane(w, h, flip) as addXyPlane / addYzPlane / addZxPlane register it (MeshFactory.h:76-126,
+    181-230, 285-335; main.cpp:43-66): a quad of two triangles named "xy" / "yz" / "zx" (+ "_flip"), material
+    LAMBERTIAN = 10 (main.cpp:20), texture index 0."""
+    hw, hh = F(F(w) / F(2)), F(F(h) / F(2))
+    if kind == "xy":
+        v = [[-hw, hh, 0], [-hw, -hh, 0], [hw, -hh, 0], [hw, hh, 0]]
+    elif kind == "yz":
+        v = [[0, hh, -hw], [0, -hh, -hw], [0, -hh, hw], [0, hh, hw]]
+    elif kind == "zx":
+        v = [[hh, 0, -hw], [-hh, 0, -hw], [-hh, 0, hw], [hh, 0, hw]]
+    else:
+        raise ValueError("plane kind must be xy, yz or zx")
+    idx = [3, 2, 1, 3, 1, 0] if flip else [0, 1, 2, 0, 2, 3]
+    return Mesh(kind + ("_flip" if flip else ""), v, idx, mat_type=10, tex_idx=tex_idx, texcoords=_FLIP_UV if flip else _UV)
+
+
+def default_texture(n: int = 64) -> np.ndarray:
+    """Stand-in for test01.png (absent; decoding images is the caller's business): an n x n RGBA8 checkerboard of
+    8 x 8 squares, computed with integers only."""
+    i = np.arange(n)
+    on = (((i[:, None] * 8) // n + (i[None, :] * 8) // n) % 2) == 0
+    t = np.zeros((n, n, 4), dtype=np.uint8)
+    t[..., 0] = np.where(on, 230, 40)
+    t[..., 1] = np.where(on, 230, 60)
+    t[..., 2] = np.where(on, 220, 160)
+    t[..., 3] = 255
+    return t
 
 
 def unit_cube_mesh(name: str = "cube") -> Mesh:

@@ -22,8 +22,9 @@ def _cross(a, b):
     return np.stack([x, y, z], axis=1).astype(F)
 
 
-def make_triangles(v0, v1, v2, mat, tex_idx: int = -1) -> np.ndarray:
-    """Triangle(v0, v1, v2, matType, texIdx) for arrays of vertices (n, 3) float32."""
+def make_triangles(v0, v1, v2, mat, tex_idx: int = -1, uv=None) -> np.ndarray:
+    """Triangle(v0, v1, v2, matType, texIdx[, u, v]) for arrays of vertices (n, 3) float32.  uv: (n, 3, 2) texture
+    coordinates of the three vertices (Mesh::genTriangles passes vec3(uv1[0], uv2[0], uv3[0]) and the same for [1])."""
     v0 = np.ascontiguousarray(v0, dtype=F)
     v1 = np.ascontiguousarray(v1, dtype=F)
     v2 = np.ascontiguousarray(v2, dtype=F)
@@ -43,6 +44,10 @@ def make_triangles(v0, v1, v2, mat, tex_idx: int = -1) -> np.ndarray:
     t["matType"] = mat
     t["shapeType"] = 0
     t["texIdx"] = tex_idx
+    if uv is not None:
+        uv = np.ascontiguousarray(uv, dtype=F).reshape(n, 3, 2)
+        t["u"] = uv[:, :, 0]
+        t["v"] = uv[:, :, 1]
     return t
 
 

@@ -37,6 +37,10 @@ class Oracle:
         lib.o_xorwow_next.argtypes = [vp]
         lib.o_xorwow_uniform.argtypes = [vp]
         lib.o_material_table.argtypes = [vp]
+        lib.o_set_texture.argtypes = [C.c_int, vp, C.c_int, C.c_int]
+        lib.o_set_texture.restype = C.c_int
+        lib.o_tex_fetch.argtypes = [C.c_int, C.c_float, C.c_float, vp]
+        lib.o_tex_fetch.restype = None
         lib.o_build_bvh.argtypes = [vp, C.c_int, vp]
         lib.o_build_bvh.restype = C.c_int
         lib.o_build_bvh_after.argtypes = [vp, C.c_int, C.c_longlong, vp]
@@ -70,6 +74,16 @@ class Oracle:
 
         out = np.zeros(50, dtype=MAT_DTYPE)
         self.lib.o_material_table(_p(out))
+        return out
+
+    def set_texture(self, idx, rgba8):
+        t = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        assert t.ndim == 3 and t.shape[2] == 4
+        assert self.lib.o_set_texture(idx, _p(t), t.shape[1], t.shape[0]) == 0
+
+    def tex_fetch(self, idx, u, v):
+        out = np.zeros(3, dtype=np.float32)
+        self.lib.o_tex_fetch(idx, C.c_float(u), C.c_float(v), _p(out))
         return out
 
     def build_bvh(self, tris, rand_calls_before=0):

@@ -349,6 +349,7 @@ def test_cpp_console_session_equals_the_python_one(oracle, tmp_path):
     if not os.path.exists(exe):
         pytest.fail("examples/console is not built: run __graft_entry__.build()")
     script = ["camera posy", "render param 80 48 3", "render", "m c1", "ry 33", "my 0.75", "s 1.5", "m cube", "rz 20",
+              "new yz", "m yz", "s 6", "mx -3", "my 2",  # a textured wall (texture 0 = the stand-in checkerboard)
               "camera posx", "render", "camera aperture 0.05", "camera dist_to_focus", "render -cache", "q"]
     out = subprocess.run([exe], input="\n".join(script) + "\n", cwd=tmp_path, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
@@ -360,7 +361,9 @@ def test_cpp_console_session_equals_the_python_one(oracle, tmp_path):
         assert "Console Error" not in con.execute(line)
     assert (tmp_path / "output.ppm").read_bytes() == (tmp_path / "py.ppm").read_bytes()
     tris = con.last_triangles
-    nodes = oracle.build_bvh(tris, calls + sg.build_rand_calls(tris.shape[0]))
+    assert (tris["texIdx"] == 0).sum() == 2
+    oracle.set_texture(0, sg.default_texture())
+    nodes = oracle.build_bvh(tris, calls + sg.build_rand_calls(689))  # the first build was over the 689 default records
     assert nodes.tobytes() == eng.getBvhNodes().tobytes()
     c = con.camera
     ocam = oracle.camera(c.position, c.position + c.front, 40.0, 80 / 48, float(c.aperture), float(c.dist_to_focus))
@@ -398,14 +401,73 @@ def test_tiny_scenes_and_frames(oracle, n_extra, nx, ny, ns):
     eng.close()
 
 
+def _textured_scene():
+    """Light quad, a textured ground quad (coordinates beyond [0, 1]: wrap), a textured wall with another texture, an
+    untextured lambertian triangle, a metal triangle that names a texture (ignored: only lambertian reads it) and
+    spheres."""
+    v = np.array([[4, 10, -4], [-4, 10, -4], [-4, 10, 4], [4, 10, 4]], dtype=np.float32)
+    g = np.array([[-8, 0, -8], [-8, 0, 8], [8, 0, 8], [8, 0, -8]], dtype=np.float32)
+    w = np.array([[-6, 0, -5], [6, 0, -5], [6, 6, -5], [-6, 6, -5]], dtype=np.float32)
+    guv = np.array([[-1.5, -1.5], [-1.5, 2.5], [2.5, 2.5], [2.5, -1.5]], dtype=np.float32)
+    wuv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=np.float32)
+    return np.concatenate([
+        scenes.make_triangles(v[[3, 3]], v[[2, 1]], v[[1, 0]], 3),
+        scenes.make_triangles(g[[0, 0]], g[[1, 2]], g[[2, 3]], 0, tex_idx=0, uv=np.stack([guv[[0, 1, 2]], guv[[0, 2, 3]]])),
+        scenes.make_triangles(w[[0, 0]], w[[1, 2]], w[[2, 3]], 8, tex_idx=5, uv=np.stack([wuv[[0, 1, 2]], wuv[[0, 2, 3]]])),
+        scenes.make_triangles(np.array([[2, 0.01, 2]], np.float32), np.array([[4, 0.01, 2]], np.float32),
+                              np.array([[3, 2, 3]], np.float32), 9),
+        scenes.make_triangles(np.array([[-4, 0.01, 2]], np.float32), np.array([[-2, 0.01, 2]], np.float32),
+                              np.array([[-3, 2.5, 1]], np.float32), 5, tex_idx=0, uv=np.array([[[0, 0], [1, 0], [0, 1]]])),
+        scenes.make_spheres(np.array([[0, 1, 0], [2.5, 0.6, 3.5]], np.float32), [1.0, 0.6], 7),
+    ])
+
+
+@pytest.mark.parametrize("kernel,fmt,topo", [(2, 1, 1), (1, 0, 0), (0, 0, 1), (3, 1, 1)])
+def test_textured_lambertian_bit_exact(oracle, kernel, fmt, topo):
+    """lambertian albedo from a texture (material.h:100-106) -- RGBA8 set through rt_set_texture,
+    sampled with the shared restatement of tex2D, hit (u, v) from the reference's barycentric blend.  Image bit-exact
+    against the oracle for every kernel variant; a missing texture is an error, not a black surface."""
+    rng = np.random.default_rng(11)
+    checker = np.zeros((8, 8, 4), dtype=np.uint8)
+    checker[..., :3] = np.where(((np.arange(8)[:, None] + np.arange(8)[None, :]) % 2)[..., None] == 0, [230, 40, 30], [250, 250, 240])
+    noise = rng.integers(0, 256, size=(5, 7, 4), dtype=np.uint8)
+    tris = _textured_scene()
+    cam = dict(lookfrom=[3, 4, 11], lookat=[0, 1.5, 0], vfov=40.0, dist_to_focus=10.0, aperture=0.0)
+    nx, ny, ns, depth = 120, 68, 6, 12
+    eng = rt_amd.PbrtEngine(nx, ny, ns, device=0)
+    for k, v in {engine.OPT_KERNEL: kernel, engine.OPT_NODE_FORMAT: fmt, engine.OPT_TOPOLOGY: topo}.items():
+        eng.setOption(k, v)
+    eng.setTriangles(tris)
+    eng.buildBvh()
+    eng.setMaxDepth(depth)
+    eng.setCamera(**cam)
+    eng.setTexture(0, checker)
+    with pytest.raises(rt_amd.RtError, match="texture 5"):
+        eng.render()
+    eng.setTexture(5, noise)
+    fb = eng.render()
+    oracle.set_texture(0, checker)
+    oracle.set_texture(5, noise)
+    nodes = oracle.build_bvh(tris)
+    assert nodes.tobytes() == eng.getBvhNodes().tobytes()
+    ocam = oracle.camera(cam["lookfrom"], cam["lookat"], 40.0, nx / ny, 0.0, 10.0)
+    fb_o, cnt = oracle.render(tris, nodes, oracle.material_table(), ocam, nx, ny, ns, depth, mode=0)
+    assert eng.last_stats.rays == cnt.rays
+    assert fb.tobytes() == fb_o.tobytes()
+    # the texture is in the picture: replacing it changes the frame
+    eng.setTexture(0, np.full((2, 2, 4), 128, dtype=np.uint8))
+    assert eng.render().tobytes() != fb.tobytes()
+    eng.close()
+
+
 def test_error_behaviour():
     eng = rt_amd.PbrtEngine(32, 32, 1, device=0)
     with pytest.raises(rt_amd.RtError, match="no scene|no camera"):
         eng.render()
     tris = scenes.heightfield(4)
     bad = tris.copy()
-    bad["texIdx"][5] = 0
-    with pytest.raises(rt_amd.RtError, match="texture"):
+    bad["texIdx"][5] = 99
+    with pytest.raises(rt_amd.RtError, match="texIdx"):
         eng.setTriangles(bad)
     sph = scenes.make_spheres(np.zeros((1, 3), np.float32), [1.0], 0)
     with pytest.raises(rt_amd.RtError, match="tri\\[0\\]"):

@@ -140,6 +140,9 @@ class FakeEngine:
     def buildBvh(self, k=0):
         self.log.append(("build", k))
 
+    def setTexture(self, idx, rgba):
+        self.log.append(("tex", idx, rgba.shape))
+
     def setCamera(self, a, b, vfov, focus, aperture):
         self.log.append(("cam", tuple(float(x) for x in a), tuple(float(x) for x in b), vfov, focus, aperture))
 
@@ -221,7 +224,15 @@ def test_console_mesh_commands(tmp_path):
     assert np.array_equal(con.last_triangles[-1]["v0"], [0, 0, 0])
     assert con.execute("s abc").startswith("Console Error:")  # std::stof throws, the loop survives
     assert con.execute("m").startswith("Console Error:")
-    assert "Console Error" in con.execute("new xy")
+    assert con.execute("new xy") == "" and "xy" in con.meshes and ("tex", 0, (64, 64, 4)) in eng.log
+    con.execute("new zy")
+    con.execute("m yz")
+    con.execute("mx -2")
+    con.execute("render")
+    t = con.last_triangles
+    yz = t[(t["texIdx"] == 0) & (t["v0"][:, 0] == -2)]
+    assert yz.shape[0] == 2 and np.all(yz["matType"] == 10) and eng.log.count(("tex", 0, (64, 64, 4))) == 1
+    assert sorted(yz["u"].reshape(-1).tolist()) == [0, 0, 0, 1, 1, 1] and np.all(t["texIdx"][t["shapeType"] == 0][:2] == -1)
     assert con.loop and con.execute("q").startswith("bye") and not con.loop
 
 
@@ -249,7 +260,8 @@ def test_cpp_scene_code_matches_this_one(tmp_path):
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "console")
     if not os.path.exists(exe):
         pytest.skip("examples/console is not built: run __graft_entry__.build()")
-    poses = ["m c7", "rx 30", "ry -75.5", "rz 10", "s 1.7", "mx 0.25", "m c12", "ry 45", "mz -3", "m cube", "rz 45", "m light", "ry 12"]
+    poses = ["m c7", "rx 30", "ry -75.5", "rz 10", "s 1.7", "mx 0.25", "m c12", "ry 45", "mz -3", "m cube", "rz 45", "m light", "ry 12",
+             "new xy", "new zx", "new zy", "m zx", "s 30", "my -0.25", "m xy", "rx 15", "mz -6"]
     for script in ([], poses):
         dump = tmp_path / "scene.bin"
         out = subprocess.run([exe, "--dump-scene", str(dump)], input="\n".join(script + ["render"]) + "\n", capture_output=True,
@@ -259,7 +271,8 @@ def test_cpp_scene_code_matches_this_one(tmp_path):
         meshes, py_calls = sg.default_meshes()
 
         class NoEngine:
-            pass
+            def setTexture(self, idx, rgba):
+                pass
 
         con = rc.Console(NoEngine(), meshes, py_calls, out_path=None)
         for line in script:
