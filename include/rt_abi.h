@@ -151,8 +151,9 @@ enum {
     /* Sample-pass sharding (NOT a parity path -- the reference's per-pixel stream is serial over samples,
      * so splitting a pixel's samples over GPUs needs other streams): */
     RT_OPT_SEED_SALT = 18,       /* added to the per-pixel seed 1995 + pixel_index (default 0 = the reference's streams) */
-    RT_OPT_RAW_SUM = 19          /* 1: the frame holds per-pixel SUMS of the (per-sample clamped) samples instead of the
+    RT_OPT_RAW_SUM = 19,         /* 1: the frame holds per-pixel SUMS of the (per-sample clamped) samples instead of the
                                     clamped mean, so that ranks' frames can be added and divided by the total count */
+    RT_OPT_QUEUE_THRESHOLD = 20  /* rt_trace_rays*: a lane takes its next ray when fewer than this many of 64 still traverse */
 };
 int rt_set_option(rt_ctx *ctx, int option, int64_t value);
 int rt_get_option(rt_ctx *ctx, int option, int64_t *value);
@@ -171,6 +172,11 @@ int rt_trace_primary(rt_ctx *ctx, int32_t *tri_id_host, float *t_host, rt_stats 
 /* Closest hit for caller-supplied rays (origin[3], direction[3] per ray, host memory). */
 int rt_trace_rays(rt_ctx *ctx, const float *org_dir6, int n_rays, int32_t *tri_id_host, float *t_host,
                   rt_stats *stats);
+
+/* The same for rays and results that live in this context's device memory (no copies; n_rays * 6 floats in,
+ * n_rays ids and n_rays t out).  Persistent waves with per-lane refill from the ray array. */
+int rt_trace_rays_device(rt_ctx *ctx, const float *org_dir6_device, int n_rays, int32_t *tri_id_device, float *t_device,
+                         rt_stats *stats);
 
 /* PPM writer of __renderScene (pbrt_engine.cu:123-133): "P3", rows top-down from j = ny-1,
  * int(255.99*c), one pixel per line, no gamma. */
@@ -198,6 +204,12 @@ int rt_test_sincosf(float x, float *s, float *c);
 /* Lane-occupancy counters of the last persistent-kernel launch (analysis builds only: `make STATS=1` builds
  * librt_amd_stats.so; the shipped library returns RT_E_UNSUPPORTED).  Layout: rt_amd/csrc/kernels.h kStat*. */
 int rt_test_trav_stats(rt_ctx *ctx, uint64_t out[16]);
+
+/* Analysis builds only (make STATS=1): record every ray of the next renders in device memory (capacity rays; 0 frees
+ * the buffer), and trace the recorded rays again with rt_trace_rays_device's kernel -- how long the traversal alone
+ * takes when taking a ray costs nothing but its loads (tools/trav_stats.py --replay). */
+int rt_test_dump_rays(rt_ctx *ctx, uint64_t capacity);
+int rt_test_trace_dumped(rt_ctx *ctx, rt_stats *stats);
 
 #ifdef __cplusplus
 }

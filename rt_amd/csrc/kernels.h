@@ -54,6 +54,9 @@ struct PersistLaunch {
     uint32_t *round_state; // kRingWords words per slot (n_local_tiles * 64 slots)
     uint32_t *round_flag;  // one word per slot; zeroed once at allocation
     uint32_t frame_id;     // never 0, below 2^26; flags of earlier launches compare unequal: no clearing per frame
+    float *ray_dump = nullptr;                     // analysis builds: rt_test_dump_rays
+    unsigned long long *ray_dump_count = nullptr;
+    unsigned long long ray_dump_cap = 0;
     unsigned long long *stats; // kTravStats counters, zeroed by the caller; only written by a -DRT_TRAV_STATS build
 };
 enum { kRingWords = 12 };
@@ -63,5 +66,8 @@ enum { kStatIters = 0, kStatNodeLanes, kStatStalledLanes, kStatIdleLanes, kStatL
 hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &F, const PersistLaunch &L, float *fb,
                              int32_t *ids, float *ts, hipStream_t stream);
 hipError_t launch_render(const KernelScene &S, const KernelFrame &F, int stack_entries, float *fb, hipStream_t stream);
+// closest hit for n rays in device memory (k_trace_queue); uses L's grid, stack, threshold, leaf batch, node format
+hipError_t launch_trace_queue(const KernelScene &S, const PersistLaunch &L, const float *rays6, uint32_t n, unsigned int *next,
+                              int32_t *ids, float *ts, unsigned long long *ray_counter, hipStream_t stream);
 
 } // namespace rtamd

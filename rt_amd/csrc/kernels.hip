@@ -16,6 +16,8 @@
 // band of tiles).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cfloat>
 #include <cstdint>
 
@@ -833,6 +835,9 @@ struct PersistArgs {
     int leaf_batch;              // SPEC: run the primitive tests when this many lanes have a leaf pending
     uint32_t total_lanes;
     unsigned long long *stats;
+    float *ray_dump;                     // analysis builds: where k_persistent records the rays it traces (or nullptr)
+    unsigned long long *ray_dump_count;
+    unsigned long long ray_dump_cap;
     int rounds;            // 1 = off
     uint32_t *round_state; // kRingWords words per slot
     uint32_t *round_flag;  // one word per slot: frame_id * 64 + the round whose start state the slot holds
@@ -1024,6 +1029,15 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                 bounce = 0;
                 need_primary = false;
             }
+#ifdef RT_TRAV_STATS
+            if (P.ray_dump) { // analysis only: every ray of the frame, in the order the waves start them
+                const unsigned long long k = atomicAdd(P.ray_dump_count, 1ull);
+                if (k < P.ray_dump_cap) {
+                    float *o = P.ray_dump + 6 * k;
+                    o[0] = cur.o.x, o[1] = cur.o.y, o[2] = cur.o.z, o[3] = cur.d.x, o[4] = cur.d.y, o[5] = cur.d.z;
+                }
+            }
+#endif
             trav_begin(T, cur);
             tracing = true;
             nr++;
@@ -1102,6 +1116,105 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
         for (int i = 0; i < kTravStats; i++)
             if (st[i]) atomicAdd(&P.stats[i], st[i]);
 #endif
+}
+
+// ------------------------------------------------------------------ closest hit for an array of rays
+// Persistent waves over a ray array: a wave takes rays 256 at a time from one counter and hands them to its lanes one
+// by one; a lane that finishes its ray writes (id, t) and takes the next as soon as fewer than `threshold` lanes are
+// still traversing -- taking a ray costs six loads, so the threshold can sit much higher than the render kernel's,
+// whose refill is a shading step.  Traversal is k_persistent's (speculative, same node and leaf code).
+struct QueueArgs {
+    const float *rays; // origin[3], direction[3] per ray
+    uint32_t n;
+    unsigned int *next; // zeroed before the launch
+    int32_t *ids;
+    float *ts;
+    unsigned long long *ray_counter;
+};
+template <int FMT>
+__global__ void __launch_bounds__(64, 6) k_trace_queue(KernelScene S, PersistArgs P, QueueArgs Q) {
+    const uint32_t lane = threadIdx.x;
+    StackRef K;
+    K.lds = s_stack + lane;
+    K.spill = P.spill + (size_t)blockIdx.x * 64u + lane;
+    K.lds_entries = P.lds_entries;
+    K.spill_stride = P.total_lanes;
+    uint32_t q_next = 0, q_end = 0; // wave-uniform: this wave's run of ray indices
+    bool exhausted = false;          // wave-uniform: the counter has passed n
+    bool tracing = false;
+    uint32_t my_ray = 0, nr = 0;
+    Ray cur;
+    cur.o = mk(0, 0, 0);
+    cur.d = mk(0, 0, 1);
+    Trav T;
+    trav_begin(T, cur);
+    for (;;) {
+        // ---- hand out rays to the idle lanes
+        for (int guard = 0; guard < 4; guard++) {
+            const unsigned long long idle = __ballot(!tracing);
+            if (idle == 0ull || exhausted) break;
+            if (q_next == q_end) {
+                uint32_t base = 0;
+                if (lane == 0u) base = atomicAdd(Q.next, 256u);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base >= Q.n) {
+                    exhausted = true;
+                    break;
+                }
+                q_next = base;
+                q_end = base + 256u < Q.n ? base + 256u : Q.n;
+            }
+            const uint32_t avail = q_end - q_next;
+            const uint32_t before = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!tracing && before < avail) {
+                my_ray = q_next + before;
+                const float2 *r = reinterpret_cast<const float2 *>(Q.rays + 6 * (size_t)my_ray);
+                const float2 a = r[0], b = r[1], c = r[2];
+                cur.o = mk(a.x, a.y, b.x);
+                cur.d = mk(b.y, c.x, c.y);
+                trav_begin(T, cur);
+                tracing = true;
+                nr++;
+            }
+            const uint32_t cnt = (uint32_t)__popcll(idle);
+            q_next += cnt < avail ? cnt : avail;
+        }
+        const unsigned long long act0 = __ballot(tracing);
+        if (act0 == 0ull) break; // nothing in flight and nothing left to take
+        // ---- traverse until enough lanes are free to make a refill worth its few instructions
+        for (;;) {
+            const unsigned long long act = __ballot(tracing);
+            if (act == 0ull) break;
+            if (!exhausted && (int)__popcll(act) < P.threshold) break;
+            if (tracing && !(T.cur & kLeafBit)) node_step<FMT>(T, S, K);
+            if (tracing && T.pend == RT_REF_NONE && T.cur != RT_REF_NONE && (T.cur & kLeafBit)) {
+                T.pend = T.cur;
+                T.cur = pop_or_none(K, T.sp);
+            }
+            const bool want_leaf = tracing && T.pend != RT_REF_NONE;
+            const unsigned long long leaf_mask = __ballot(want_leaf);
+            if (leaf_mask != 0ull) {
+                const unsigned long long node_mask = __ballot(tracing && !(T.cur & kLeafBit));
+                if (node_mask == 0ull || (int)__popcll(leaf_mask) >= P.leaf_batch) {
+                    if (want_leaf) {
+                        leaf_test(T, S, cur, T.pend);
+                        T.pend = RT_REF_NONE;
+                    }
+                }
+            }
+            if (tracing && T.cur == RT_REF_NONE && T.pend == RT_REF_NONE) {
+                tracing = false;
+                if (T.best_rank != RT_NO_HIT) {
+                    Q.ids[my_ray] = __float_as_int(S.prims[3 * (size_t)T.best_rank + 2].z);
+                    Q.ts[my_ray] = T.best_t;
+                } else {
+                    Q.ids[my_ray] = -1;
+                    Q.ts[my_ray] = 0.0f;
+                }
+            }
+        }
+    }
+    add_rays(Q.ray_counter, nr);
 }
 
 // ------------------------------------------------------------------ two paths per lane
@@ -1355,6 +1468,33 @@ hipError_t launch_trace_rays(const KernelScene &S, int stack_entries, const floa
     return hipGetLastError();
 }
 
+hipError_t launch_trace_queue(const KernelScene &S, const PersistLaunch &L, const float *rays6, uint32_t n, unsigned int *next,
+                              int32_t *ids, float *ts, unsigned long long *ray_counter, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    if (L.lds_entries < 1 || L.grid_waves < 1) return hipErrorInvalidValue;
+    const size_t lds = (size_t)L.lds_entries * 64 * sizeof(uint32_t);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    PersistArgs P = {};
+    P.spill = L.spill;
+    P.lds_entries = L.lds_entries;
+    P.threshold = L.threshold;
+    P.leaf_batch = L.leaf_batch;
+    P.total_lanes = (uint32_t)L.grid_waves * 64u;
+    QueueArgs Q;
+    Q.rays = rays6;
+    Q.n = n;
+    Q.next = next;
+    Q.ids = ids;
+    Q.ts = ts;
+    Q.ray_counter = ray_counter;
+    const uint32_t waves = std::min<uint32_t>((uint32_t)L.grid_waves, (n + 63u) / 64u);
+    if (L.node_format == 0)
+        hipLaunchKernelGGL((k_trace_queue<0>), dim3(waves), dim3(64), lds, stream, S, P, Q);
+    else
+        hipLaunchKernelGGL((k_trace_queue<1>), dim3(waves), dim3(64), lds, stream, S, P, Q);
+    return hipGetLastError();
+}
+
 hipError_t launch_render(const KernelScene &S, const KernelFrame &F, int stack_entries, float *fb, hipStream_t stream) {
     size_t lds;
     if (lds_bytes_ok(stack_entries, lds) != hipSuccess) return hipErrorInvalidValue;
@@ -1377,6 +1517,9 @@ hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &
     P.leaf_batch = L.leaf_batch;
     P.total_lanes = (uint32_t)L.grid_waves * 64u;
     P.stats = L.stats;
+    P.ray_dump = L.ray_dump;
+    P.ray_dump_count = L.ray_dump_count;
+    P.ray_dump_cap = L.ray_dump_cap;
     P.rounds = mode == 0 && L.rounds > 1 ? L.rounds : 1;
     P.round_state = L.round_state;
     P.round_flag = L.round_flag;

@@ -37,6 +37,11 @@ struct rt_ctx {
     uint32_t frame_id = 0;
     unsigned long long seed_salt = 0;
     int raw_sum = 0;
+    int queue_threshold = 48; // k_trace_queue: hand out rays when fewer lanes than this still traverse
+    // analysis builds: rays recorded by the last render (rt_test_dump_rays)
+    float *d_ray_dump = nullptr;
+    unsigned long long *d_ray_dump_count = nullptr;
+    unsigned long long ray_dump_cap = 0;
     // textures (lambertian albedo of triangles with texIdx != -1)
     void *d_uv = nullptr;
     DevTex *d_tex = nullptr;               // RT_TEX_NUM descriptors
@@ -337,6 +342,12 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L, bool render) {
         L.frame_id = c->frame_id;
     }
     L.stats = reinterpret_cast<unsigned long long *>(c->d_bands + 16);
+    if (render && c->d_ray_dump) {
+        L.ray_dump = c->d_ray_dump;
+        L.ray_dump_count = c->d_ray_dump_count;
+        L.ray_dump_cap = c->ray_dump_cap;
+        HIPCHK(c, hipMemsetAsync(c->d_ray_dump_count, 0, sizeof(unsigned long long), c->stream));
+    }
     HIPCHK(c, hipMemsetAsync(c->d_bands, 0, kBandBytes, c->stream));
     return RT_OK;
 }
@@ -442,6 +453,8 @@ int rt_destroy(rt_ctx *c) {
     if (c->d_mats) (void)hipFree(c->d_mats);
     if (c->d_counter) (void)hipFree(c->d_counter);
     if (c->d_bands) (void)hipFree(c->d_bands);
+    if (c->d_ray_dump) (void)hipFree(c->d_ray_dump);
+    if (c->d_ray_dump_count) (void)hipFree(c->d_ray_dump_count);
     if (c->d_tex) (void)hipFree(c->d_tex);
     for (int i = 0; i < RT_TEX_NUM; i++)
         if (c->d_texels[i]) (void)hipFree(c->d_texels[i]);
@@ -614,6 +627,10 @@ int rt_set_option(rt_ctx *c, int option, int64_t value) {
         if (value < 1 || value > 64) return fail(c, RT_E_ARG, "swap batch 1..64");
         c->swap_batch = (int)value;
         return RT_OK;
+    case RT_OPT_QUEUE_THRESHOLD:
+        if (value < 1 || value > 64) return fail(c, RT_E_ARG, "queue threshold 1..64");
+        c->queue_threshold = (int)value;
+        return RT_OK;
     case RT_OPT_SEED_SALT:
         if (value < 0) return fail(c, RT_E_ARG, "seed salt must not be negative");
         c->seed_salt = (unsigned long long)value;
@@ -657,6 +674,7 @@ int rt_get_option(rt_ctx *c, int option, int64_t *value) {
     case RT_OPT_TAIL_SPLIT: *value = c->tail_split; return RT_OK;
     case RT_OPT_SEED_SALT: *value = (int64_t)c->seed_salt; return RT_OK;
     case RT_OPT_RAW_SUM: *value = c->raw_sum; return RT_OK;
+    case RT_OPT_QUEUE_THRESHOLD: *value = c->queue_threshold; return RT_OK;
     default: return fail(c, RT_E_ARG, "unknown option");
     }
 }
@@ -788,8 +806,19 @@ int rt_trace_rays(rt_ctx *c, const float *org_dir6, int n_rays, int32_t *tri_id_
             break;
         if ((e = hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream)) != hipSuccess) break;
         if ((e = hipEventRecord(c->ev0, c->stream)) != hipSuccess) break;
-        if ((e = launch_trace_rays(scene_of(c), c->wide.stack_entries, d_rays, n_rays, d_ids, d_ts, c->d_counter,
-                                   c->stream)) != hipSuccess)
+        if (c->kernel_variant >= 1) {
+            PersistLaunch L;
+            if (prepare_persistent(c, L, false) != RT_OK) {
+                e = hipErrorOutOfMemory;
+                break;
+            }
+            L.threshold = c->queue_threshold;
+            if ((e = hipEventRecord(c->ev0, c->stream)) != hipSuccess) break; // after the set-up memsets
+            if ((e = launch_trace_queue(scene_of(c), L, d_rays, (uint32_t)n_rays, c->d_bands, d_ids, d_ts, c->d_counter,
+                                        c->stream)) != hipSuccess)
+                break;
+        } else if ((e = launch_trace_rays(scene_of(c), c->wide.stack_entries, d_rays, n_rays, d_ids, d_ts, c->d_counter,
+                                          c->stream)) != hipSuccess)
             break;
         if ((e = hipEventRecord(c->ev1, c->stream)) != hipSuccess) break;
         if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) break;
@@ -869,6 +898,70 @@ int rt_test_trav_stats(rt_ctx *c, uint64_t out[16]) {
 #else
     return fail(c, RT_E_UNSUPPORTED, "built without RT_TRAV_STATS (make STATS=1 builds librt_amd_stats.so)");
 #endif
+}
+
+int rt_trace_rays_device(rt_ctx *c, const float *org_dir6_device, int n_rays, int32_t *tri_id_device, float *t_device,
+                         rt_stats *st) {
+    if (!c || !org_dir6_device || !tri_id_device || !t_device || n_rays <= 0) return RT_E_ARG;
+    double t0 = now_ms();
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ready_to_trace(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
+    PersistLaunch L;
+    rc = prepare_persistent(c, L, false);
+    if (rc) return rc;
+    L.threshold = c->queue_threshold;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    HIPCHK(c, launch_trace_queue(scene_of(c), L, org_dir6_device, (uint32_t)n_rays, c->d_bands, tri_id_device, t_device,
+                                 c->d_counter, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0.0f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    unsigned long long rays = 0;
+    HIPCHK(c, hipMemcpy(&rays, c->d_counter, sizeof(rays), hipMemcpyDeviceToHost));
+    fill_stats(c, st, rays, ms, now_ms() - t0);
+    return RT_OK;
+}
+
+int rt_test_dump_rays(rt_ctx *c, uint64_t capacity) {
+    if (!c) return RT_E_ARG;
+#ifdef RT_TRAV_STATS
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->d_ray_dump) (void)hipFree(c->d_ray_dump);
+    c->d_ray_dump = nullptr;
+    c->ray_dump_cap = 0;
+    if (capacity == 0) return RT_OK;
+    if (!c->d_ray_dump_count) HIPCHK(c, hipMalloc((void **)&c->d_ray_dump_count, sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc((void **)&c->d_ray_dump, capacity * 6 * sizeof(float)));
+    c->ray_dump_cap = capacity;
+    return RT_OK;
+#else
+    (void)capacity;
+    return fail(c, RT_E_UNSUPPORTED, "built without RT_TRAV_STATS (make STATS=1 builds librt_amd_stats.so)");
+#endif
+}
+
+int rt_test_trace_dumped(rt_ctx *c, rt_stats *st) {
+    if (!c) return RT_E_ARG;
+    if (!c->d_ray_dump) return fail(c, RT_E_ARG, "no recorded rays: rt_test_dump_rays, then render");
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned long long n = 0;
+    HIPCHK(c, hipMemcpy(&n, c->d_ray_dump_count, sizeof(n), hipMemcpyDeviceToHost));
+    if (n > c->ray_dump_cap) n = c->ray_dump_cap;
+    if (n == 0 || n > 0x7FFFFFFFull) return fail(c, RT_E_LIMIT, "recorded ray count out of range");
+    int32_t *d_ids = nullptr;
+    float *d_ts = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_ids, n * sizeof(int32_t)));
+    if (hipMalloc((void **)&d_ts, n * sizeof(float)) != hipSuccess) {
+        (void)hipFree(d_ids);
+        return fail(c, RT_E_HIP, "out of device memory");
+    }
+    int rc = rt_trace_rays_device(c, c->d_ray_dump, (int)n, d_ids, d_ts, st);
+    (void)hipFree(d_ids);
+    (void)hipFree(d_ts);
+    return rc;
 }
 
 int rt_test_sincosf(float x, float *s, float *c) {

@@ -39,6 +39,7 @@ MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_LIGHT = 0, 1, 2, 3
 OPT_MAX_DEPTH, OPT_HONOR_VFOV, OPT_LEAF_SIZE, OPT_BOX_MODE, OPT_SHARD_RANK, OPT_SHARD_WORLD, OPT_KERNEL = 1, 2, 3, 4, 5, 6, 7
 OPT_REFILL_THRESHOLD, OPT_WAVES_PER_CU, OPT_LDS_STACK, OPT_NODE_FORMAT, OPT_LEAF_BATCH, OPT_OCCUPANCY, OPT_TOPOLOGY = 8, 9, 10, 11, 12, 13, 14
 OPT_SHADE_BATCH, OPT_SWAP_BATCH, OPT_TAIL_SPLIT, OPT_SEED_SALT, OPT_RAW_SUM = 15, 16, 17, 18, 19
+OPT_QUEUE_THRESHOLD = 20
 
 
 class RtStats(C.Structure):
@@ -65,7 +66,8 @@ ABI_SYMBOLS = [
     "rt_set_bvh_nodes", "rt_get_bvh_nodes", "rt_default_materials", "rt_set_materials", "rt_set_camera",
     "rt_set_option", "rt_get_option", "rt_render", "rt_render_device", "rt_trace_primary", "rt_trace_rays",
     "rt_write_ppm", "rt_test_glibc_rand", "rt_test_introsort", "rt_test_build_bvh", "rt_test_wide_layout", "rt_test_tile_owner",
-    "rt_test_trav_stats", "rt_test_sincosf", "rt_set_texture",
+    "rt_test_trav_stats", "rt_test_sincosf", "rt_set_texture", "rt_trace_rays_device", "rt_test_dump_rays",
+    "rt_test_trace_dumped",
 ]
 
 
@@ -92,6 +94,9 @@ def load_library(path: str = LIB_PATH):
     lib.rt_set_materials.argtypes = [vp, vp, C.c_int]
     lib.rt_set_camera.argtypes = [vp, fp, fp, C.c_float, C.c_float, C.c_float]
     lib.rt_set_texture.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int]
+    lib.rt_trace_rays_device.argtypes = [vp, vp, C.c_int, vp, vp, C.POINTER(RtStats)]
+    lib.rt_test_dump_rays.argtypes = [vp, C.c_uint64]
+    lib.rt_test_trace_dumped.argtypes = [vp, C.POINTER(RtStats)]
     lib.rt_set_option.argtypes = [vp, C.c_int, C.c_int64]
     lib.rt_get_option.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
     lib.rt_render.argtypes = [vp, vp, C.POINTER(RtStats)]

@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--occ", type=int, default=None)
     ap.add_argument("--waves", type=int, default=None)
     ap.add_argument("--tail", type=int, default=None)
+    ap.add_argument("--replay", type=str, default=None, metavar="T1,T2,...",
+                    help="record the frame's rays and trace them again with the ray-array kernel at these hand-out thresholds")
     args = ap.parse_args()
     eng = rt_amd.PbrtEngine(args.nx, args.ny, args.spp, device=0)
     if args.threshold is not None:
@@ -70,7 +72,20 @@ def main():
     eng.buildBvh()
     eng.setMaxDepth(args.depth)
     eng.setCamera(**scenes.BENCH_CAMERA)
+    if args.replay:
+        eng._check(eng._lib.rt_test_dump_rays(eng._h, 40 * args.nx * args.ny * args.spp // 10), "rt_test_dump_rays")
     eng.render()
+    if args.replay:
+        rays, render_ms = int(eng.last_stats.rays), eng.last_stats.kernel_ms
+        for thr in [int(x) for x in args.replay.split(",")]:
+            eng.setOption(E.OPT_QUEUE_THRESHOLD, thr)
+            for _ in range(2):
+                eng._check(eng._lib.rt_test_trace_dumped(eng._h, C.byref(eng.last_stats)), "rt_test_trace_dumped")
+            print(json.dumps({"kind": "replay", "threshold": thr, "rays": int(eng.last_stats.rays), "render_rays": rays,
+                              "render_ms_stats_build": render_ms, "replay_ms": eng.last_stats.kernel_ms,
+                              "mrays_s": eng.last_stats.rays / eng.last_stats.kernel_ms / 1e3}), flush=True)
+        eng._check(eng._lib.rt_test_dump_rays(eng._h, 0), "rt_test_dump_rays")
+        return
     d = stats(eng)
     d.update(kind="render", kernel_ms=eng.last_stats.kernel_ms, rays=int(eng.last_stats.rays))
     d["node_steps_per_ray"] = d["node_lanes"] / d["rays"]
