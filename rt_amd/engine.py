@@ -333,6 +333,12 @@ class PbrtEngine:
                     "rt_trace_rays")
         return ids, ts
 
+    def traceRaysDevice(self, rays_ptr: int, n: int, ids_ptr: int, ts_ptr: int) -> RtStats:
+        """Closest hits for n rays already in this GPU's memory (6 floats each); ids (int32) and t (float32) stay there."""
+        self._check(self._lib.rt_trace_rays_device(self._h, C.c_void_p(rays_ptr), n, C.c_void_p(ids_ptr), C.c_void_p(ts_ptr),
+                                                   C.byref(self.last_stats)), "rt_trace_rays_device")
+        return self.last_stats
+
     def renderScene(self, _buildScene: bool = True, out_path: str = "./output.ppm", file=sys.stdout) -> np.ndarray:
         """renderScene + __renderScene + join (pbrt_engine.cu:89-157): same stdout lines, same PPM bytes."""
         print(f"rendering a {self.nx}[width]x{self.ny}[height] image with {self.ns} samples per pixel in "

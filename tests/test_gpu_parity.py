@@ -372,6 +372,52 @@ def test_cpp_console_session_equals_the_python_one(oracle, tmp_path):
     eng.close()
 
 
+@pytest.mark.parametrize("thr,n", [(48, 100000), (64, 777), (1, 5000), (48, 1)])
+def test_trace_rays_device_equals_host_path_and_oracle(oracle, thr, n):
+    """rt_trace_rays_device (rays and results in device memory, persistent waves with per-lane refill) against
+    rt_trace_rays and, on a sample, the oracle: ids and t bit-exact, for hand-out thresholds from 1 to 64 and ray
+    counts that do not fill a wave or a chunk."""
+    import ctypes as C
+
+    # device buffers straight from the HIP runtime the library already loaded (torch would bring a second runtime
+    # into this process when imported after it)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+
+    def dmalloc(nbytes):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), nbytes) == 0
+        return p
+
+    tris = scenes.heightfield(40)
+    eng = _engine(tris, 32, 32, 1, 8, scenes.BENCH_CAMERA, {engine.OPT_QUEUE_THRESHOLD: thr})
+    rng = np.random.default_rng(n)
+    org = rng.uniform(-9, 9, size=(n, 3)).astype(np.float32)
+    org[:, 1] = rng.uniform(0.5, 12, size=n).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    rays = np.concatenate([org, d], axis=1)
+    ids_h, ts_h = eng.traceRays(rays)
+    d_rays, d_ids, d_ts = dmalloc(rays.nbytes), dmalloc(4 * n), dmalloc(4 * n)
+    ids_d, ts_d = np.full(n, -7, dtype=np.int32), np.full(n, -7.0, dtype=np.float32)
+    assert hip.hipMemcpy(d_rays, rays.ctypes.data_as(C.c_void_p), rays.nbytes, 1) == 0  # host to device
+    assert hip.hipMemcpy(d_ids, ids_d.ctypes.data_as(C.c_void_p), 4 * n, 1) == 0
+    assert hip.hipMemcpy(d_ts, ts_d.ctypes.data_as(C.c_void_p), 4 * n, 1) == 0
+    st = eng.traceRaysDevice(d_rays.value, n, d_ids.value, d_ts.value)
+    assert st.rays == n
+    assert hip.hipMemcpy(ids_d.ctypes.data_as(C.c_void_p), d_ids, 4 * n, 2) == 0  # device to host
+    assert hip.hipMemcpy(ts_d.ctypes.data_as(C.c_void_p), d_ts, 4 * n, 2) == 0
+    for p in (d_rays, d_ids, d_ts):
+        hip.hipFree(p)
+    assert ids_d.tobytes() == ids_h.tobytes() and ts_d.tobytes() == ts_h.tobytes()
+    nodes = eng.getBvhNodes()
+    for k in range(0, n, max(1, n // 50)):
+        hit, tid, t, _ = oracle.hit(tris, nodes, org[k], d[k])
+        assert (tid if hit else -1) == ids_h[k] and (np.float32(t) if hit else np.float32(0)) == ts_h[k]
+    eng.close()
+
+
 @pytest.mark.parametrize("n_extra,nx,ny,ns", [(0, 17, 9, 3), (1, 1, 1, 5), (2, 8, 8, 1), (5, 33, 2, 9)])
 def test_tiny_scenes_and_frames(oracle, n_extra, nx, ny, ns):
     """The small end: one, two, three and six primitives (a one-node tree; leaves that are the whole scene), frames of
