@@ -80,10 +80,12 @@ def valu_issue(kernel_s):
     tools/pmc_passes.sh): wave64 VALU instructions x 4 cycles over the cycles of 1024 SIMDs.  Not measured live."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-        k = [x for x in d if "k_persistent<0, 1, 1, 6>" in x][0]
+        k = [x for x in d if "k_persistent<0, 1, 1, 6" in x][0]
         v = {c: x["per_dispatch"] for c, x in d[k].items()}
         cycles = v["GRBM_GUI_ACTIVE"] / 8.0  # summed over 8 XCDs
         return {"source": "profiles/r01_pmc_summary.json", "valu_insts_per_launch": v["SQ_INSTS_VALU"],
+                # 4 cycles per wave64 instruction; quarter-rate ones (rcp, sqrt, f64 divide steps) take longer, so the
+                # estimate can pass 1: read it as "the VALU pipe never idles"
                 "busy_frac": v["SQ_INSTS_VALU"] / 1024.0 * 4.0 / cycles,
                 "lane_utilisation": v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0)}
     except Exception:
@@ -252,7 +254,7 @@ def main():
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "kernel": "k_persistent<0,1,1,6> (render, quantized nodes, speculative, 8 rounds)",
+                    "traffic": traffic, "kernel": "k_persistent<0,1,1,6,false> (render, quantized nodes, speculative, 8 rounds)",
                     "kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_ray": bytes_per_ray, "bytes_per_ray_source": bytes_source,
                     "rays_per_launch": rays_per_launch,
                     # frac > 1 is not an error: SURVEY 8d prices every box test of a binary-tree traversal at 32 HBM
