@@ -506,6 +506,53 @@ def test_textured_lambertian_bit_exact(oracle, kernel, fmt, topo):
     eng.close()
 
 
+def test_calls_from_other_host_threads_and_two_contexts():
+    """The reference creates the engine on its main thread, resizes from the console thread and renders on a worker
+    thread (main.cpp:195-220; pbrt_engine.cu:148).  Here: build on the main thread, resize on a second, render on a
+    third, while another context renders a different scene at the same time -- the frames are those of a plain
+    single-thread run."""
+    import threading
+
+    tris_a, tris_b = scenes.heightfield(48), scenes.spheres_scene(4)
+    plain_a = _engine(tris_a, 100, 60, 3, 8, scenes.BENCH_CAMERA)
+    want_a = plain_a.render()
+    plain_a.close()
+    plain_b = _engine(tris_b, 70, 40, 4, 20, scenes.DEFAULT_CAMERA)
+    want_b = plain_b.render()
+    plain_b.close()
+
+    a = _engine(tris_a, 64, 64, 1, 8, scenes.BENCH_CAMERA)
+    b = _engine(tris_b, 70, 40, 4, 20, scenes.DEFAULT_CAMERA)
+    out, errs = {}, []
+
+    def resize():
+        try:
+            a.setNx(100), a.setNy(60), a.setNs(3)
+            a.uponPixelNumChange()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    def render(name, eng):
+        try:
+            for _ in range(3):
+                out[name] = eng.render()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    t = threading.Thread(target=resize)
+    t.start()
+    t.join()
+    ts = [threading.Thread(target=render, args=("a", a)), threading.Thread(target=render, args=("b", b))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert out["a"].tobytes() == want_a.tobytes() and out["b"].tobytes() == want_b.tobytes()
+    a.close()
+    b.close()
+
+
 def test_error_behaviour():
     eng = rt_amd.PbrtEngine(32, 32, 1, device=0)
     with pytest.raises(rt_amd.RtError, match="no scene|no camera"):
