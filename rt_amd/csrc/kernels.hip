@@ -1074,6 +1074,11 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                     const int nl = __popcll(__ballot(tracing && !(T.cur & kLeafBit)));
                     RT_STAT(kStatNodeLanes, nl);
                     RT_STAT(kStatNodeIters, nl != 0);
+                    for (int bb = 0; bb < 8; bb++) { // divergence per bounce: lanes of each bounce depth testing a node
+                        const int nb = __popcll(__ballot(tracing && !(T.cur & kLeafBit) && (bounce < 7 ? bounce : 7) == bb));
+                        RT_STAT(kStatNodeLanesByBounce + bb, nb);
+                        RT_STAT(kStatItersWithBounce + bb, nb != 0);
+                    }
                     RT_STAT(kStatStalledLanes, __popcll(__ballot(tracing && T.cur != RT_REF_NONE && (T.cur & kLeafBit) && T.pend != RT_REF_NONE)));
                 }
 #endif

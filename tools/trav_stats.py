@@ -20,7 +20,7 @@ NAMES = ["iters", "node_lanes", "stalled_lanes", "idle_lanes", "leaf_fires", "le
 
 
 def stats(eng):
-    out = np.zeros(16, dtype=np.uint64)
+    out = np.zeros(32, dtype=np.uint64)
     eng._check(eng._lib.rt_test_trav_stats(eng._h, out.ctypes.data_as(C.c_void_p)), "rt_test_trav_stats")
     d = {n: int(out[i]) for i, n in enumerate(NAMES)}
     it = max(d["iters"], 1)
@@ -33,6 +33,10 @@ def stats(eng):
     d["leaf_lanes_per_fire"] = d["leaf_lanes"] / max(d["leaf_fires"], 1)
     d["leaf_prims_per_lane"] = d["leaf_prims"] / max(d["leaf_lanes"], 1)
     d["iters_per_leaf_fire"] = it / max(d["leaf_fires"], 1)
+    # per bounce depth (0 = primary ray, 7 = seventh bounce and beyond): lanes testing a node, averaged over the
+    # iterations in which that depth was present in the wave at all, and that depth's share of all node tests
+    d["node_lanes_by_bounce"] = [int(out[16 + b]) / max(int(out[24 + b]), 1) for b in range(8)]
+    d["node_share_by_bounce"] = [int(out[16 + b]) / max(d["node_lanes"], 1) for b in range(8)]
     d["shade_lanes_per_refill"] = d["shade_lanes"] / max(d["refills"], 1)
     d["iters_per_refill"] = it / max(d["refills"], 1)
     return d
