@@ -203,7 +203,7 @@ int rt_test_sincosf(float x, float *s, float *c);
 
 /* Lane-occupancy counters of the last persistent-kernel launch (analysis builds only: `make STATS=1` builds
  * librt_amd_stats.so; the shipped library returns RT_E_UNSUPPORTED).  Layout: rt_amd/csrc/kernels.h kStat*. */
-int rt_test_trav_stats(rt_ctx *ctx, uint64_t out[32]);
+int rt_test_trav_stats(rt_ctx *ctx, uint64_t out[40]);
 
 /* Analysis builds only (make STATS=1): record every ray of the next renders in device memory (capacity rays; 0 frees
  * the buffer), and trace the recorded rays again with rt_trace_rays_device's kernel -- how long the traversal alone

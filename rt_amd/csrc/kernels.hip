@@ -911,6 +911,9 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
     for (;;) {
         // ---------------- refill phase: lanes that are not traversing
         RT_STAT(kStatRefills, 1);
+#ifdef RT_TRAV_STATS
+        const unsigned long long clk0 = __builtin_readcyclecounter();
+#endif
         since_poll = 0;
         bool want_push = false;
         RT_STAT(kStatShadeLanes, __popcll(__ballot(has_pixel && result_ready)));
@@ -955,6 +958,10 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                 }
             }
         }
+#ifdef RT_TRAV_STATS
+        const unsigned long long clk_shade = __builtin_readcyclecounter();
+        RT_STAT(kStatShadeClocks, clk_shade - clk0);
+#endif
         if (ring_on && want_push) { // end of this round's share: publish state, drain, flag
             const uint32_t my_slot = slot_round & 0x3FFFFFFu;
             uint32_t *sp = P.round_state + (size_t)my_slot * kRingWords;
@@ -1050,6 +1057,10 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
             __builtin_amdgcn_s_sleep(127);
         }
 
+#ifdef RT_TRAV_STATS
+        const unsigned long long clk1 = __builtin_readcyclecounter();
+        RT_STAT(kStatRefillClocks, clk1 - clk0);
+#endif
         // ---------------- traversal phase
         for (;;) {
             const unsigned long long act = __ballot(tracing);
@@ -1114,6 +1125,9 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                 }
             }
         }
+#ifdef RT_TRAV_STATS
+        RT_STAT(kStatTravClocks, __builtin_readcyclecounter() - clk1);
+#endif
     }
     add_rays(F.ray_counter, nr);
 #ifdef RT_TRAV_STATS

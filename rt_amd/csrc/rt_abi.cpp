@@ -889,7 +889,7 @@ int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *
     return RT_OK;
 }
 
-int rt_test_trav_stats(rt_ctx *c, uint64_t out[32]) {
+int rt_test_trav_stats(rt_ctx *c, uint64_t out[40]) {
     if (!c || !out) return RT_E_ARG;
 #ifdef RT_TRAV_STATS
     if (hipSetDevice(c->device) != hipSuccess) return RT_E_HIP;

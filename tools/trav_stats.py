@@ -20,7 +20,7 @@ NAMES = ["iters", "node_lanes", "stalled_lanes", "idle_lanes", "leaf_fires", "le
 
 
 def stats(eng):
-    out = np.zeros(32, dtype=np.uint64)
+    out = np.zeros(40, dtype=np.uint64)
     eng._check(eng._lib.rt_test_trav_stats(eng._h, out.ctypes.data_as(C.c_void_p)), "rt_test_trav_stats")
     d = {n: int(out[i]) for i, n in enumerate(NAMES)}
     it = max(d["iters"], 1)
@@ -37,6 +37,9 @@ def stats(eng):
     # iterations in which that depth was present in the wave at all, and that depth's share of all node tests
     d["node_lanes_by_bounce"] = [int(out[16 + b]) / max(int(out[24 + b]), 1) for b in range(8)]
     d["node_share_by_bounce"] = [int(out[16 + b]) / max(d["node_lanes"], 1) for b in range(8)]
+    clocks = float(int(out[32]) + int(out[33])) or 1.0  # wave clocks (s_memtime domain), summed over waves
+    d["wave_time_share"] = {"refill_phase": int(out[32]) / clocks, "of_which_shading": int(out[34]) / clocks,
+                            "traversal_phase": int(out[33]) / clocks}
     d["shade_lanes_per_refill"] = d["shade_lanes"] / max(d["refills"], 1)
     d["iters_per_refill"] = it / max(d["refills"], 1)
     return d
