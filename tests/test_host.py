@@ -237,3 +237,36 @@ def test_scene_generators_are_deterministic():
     assert (a["texIdx"] == -1).all()
     assert np.isfinite(a["normal"]).all()
     assert scenes.heightfield(224).shape[0] == 100352 + 2
+
+
+def test_null_context_is_an_error_not_a_crash():
+    """No GPU here, so no context can exist: every entry point that takes one must refuse a null handle with a
+    status code (nothing exits or throws across the boundary, rt_abi.h), and rt_create must fail loudly."""
+    import ctypes as C
+
+    lib = engine.load_library()
+    h = C.c_void_p()
+    rc = lib.rt_create(C.byref(h), 0)
+    if rc == 0:  # a GPU is present after all: nothing to check here
+        lib.rt_destroy(h)
+        pytest.skip("a HIP device is available")
+    assert rc != 0 and not h.value
+    null, buf = C.c_void_p(), (C.c_float * 16)()
+    i64 = C.c_int64()
+    assert lib.rt_resize(null, 8, 8, 1) != 0
+    assert lib.rt_set_scene(null, buf, 1) != 0
+    assert lib.rt_build_bvh(null, 0) != 0
+    assert lib.rt_set_bvh_nodes(null, buf, 1) != 0
+    assert lib.rt_get_bvh_nodes(null, None, 0, C.byref(C.c_int())) != 0
+    assert lib.rt_set_materials(null, buf, 1) != 0
+    assert lib.rt_set_texture(null, 0, buf, 1, 1) != 0
+    assert lib.rt_set_camera(null, (C.c_float * 3)(), (C.c_float * 3)(), 40.0, 10.0, 0.0) != 0
+    assert lib.rt_set_option(null, 1, 5) != 0 and lib.rt_get_option(null, 1, C.byref(i64)) != 0
+    assert lib.rt_render(null, buf, None) != 0 and lib.rt_render_device(null, buf, None) != 0
+    assert lib.rt_trace_primary(null, buf, buf, None) != 0
+    assert lib.rt_trace_rays(null, buf, 1, buf, buf, None) != 0
+    assert lib.rt_trace_rays_device(null, buf, 1, buf, buf, None) != 0
+    lib.rt_destroy(null)  # destroying nothing must not crash; its status is not specified
+    assert lib.rt_write_ppm(None, buf, 1, 1) != 0
+    with pytest.raises(engine.RtError, match="no usable HIP device"):
+        engine.PbrtEngine(8, 8, 1)
