@@ -290,10 +290,16 @@ void fill_stats(rt_ctx *c, rt_stats *st, uint64_t rays, float ms, double total_m
 
 // kernel variant 1: zero the band counters, size the spill area, fill the launch record
 int prepare_persistent(rt_ctx *c, PersistLaunch &L, bool render) {
-    // primary rays are short and coherent: 16 waves per CU measured 20 % faster than 24 (2.4 vs 2.0 Grays/s at 1080p)
-    // textured scenes run the 128-VGPR instances (4 waves/SIMD): no point in launching more waves than are resident
-    const bool four_per_simd = !render || !c->wide.uv.empty();
-    L.grid_waves = c->n_cus * (four_per_simd ? std::min(c->waves_per_cu, 16) : c->waves_per_cu);
+    // Render: waves_per_cu.  Textured scenes run the 128-VGPR instances (4 waves/SIMD): no point in launching more
+    // waves than are resident.  Primary rays / ray arrays are short and coherent, and every wave launched costs a ramp
+    // of atomics and first misses: 8 waves per CU measured best (1 M triangles, 1080p: 0.65 ms vs 0.86 at 16 and 1.06
+    // at 24; 4K: 1.77 vs 1.95 ms).
+    int per_cu = c->waves_per_cu;
+    if (!render)
+        per_cu = std::min(per_cu, 8);
+    else if (!c->wide.uv.empty())
+        per_cu = std::min(per_cu, 16);
+    L.grid_waves = c->n_cus * per_cu;
     L.lds_entries = c->lds_stack < c->wide.stack_entries ? c->lds_stack : c->wide.stack_entries;
     L.threshold = c->refill_threshold;
     L.node_format = c->node_format;
