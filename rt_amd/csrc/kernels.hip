@@ -586,7 +586,7 @@ __global__ void __launch_bounds__(64) k_render(KernelScene S, KernelFrame F, flo
 // hipcc sinks a load into the branch that first uses it; for a node that turns one memory round trip per
 // traversal step into two (boxes, then child references).  Naming the values in an empty asm statement pins
 // every load of the node before the first use of any of them.
-#define RT_PIN4(V) asm volatile("" : "+v"((V).x), "+v"((V).y), "+v"((V).z), "+v"((V).w))
+#define RT_PIN4(V) asm volatile("" ::"v"((V).x), "v"((V).y), "v"((V).z), "v"((V).w))
 
 #define RT_REF_NONE 0xFFFFFFFFu /* "no node": has the leaf bit set but is never a real leaf reference */
 struct Trav {
@@ -596,10 +596,10 @@ struct Trav {
     int best_rank;
     uint32_t cur;
     uint32_t pend; // speculative traversal: one postponed leaf
-    int sp;
+    uint32_t sp;   // LDS address of the next free stack entry of this lane: stack base + entry * 256 + lane * 4
 };
 
-__device__ __forceinline__ void trav_begin(Trav &T, const Ray &r) {
+__device__ __forceinline__ void trav_begin(Trav &T, const Ray &r, uint32_t sp0) {
     T.idx = safe_inv(r.d.x);
     T.idy = safe_inv(r.d.y);
     T.idz = safe_inv(r.d.z);
@@ -613,7 +613,7 @@ __device__ __forceinline__ void trav_begin(Trav &T, const Ray &r) {
     T.best_rank = RT_NO_HIT;
     T.cur = 0;
     T.pend = RT_REF_NONE;
-    T.sp = 0;
+    T.sp = sp0;
 }
 
 // Accesses that must name global memory (a volatile or atomic access through a generic pointer becomes flat_*, which
@@ -628,29 +628,59 @@ __device__ __forceinline__ void st_sc1(uint32_t *p, uint32_t v) {
     __hip_atomic_store((gu32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// LDS through address-space-3 pointers and byte offsets: ds_read / ds_write with the offset in one register
+typedef __attribute__((address_space(3))) uint32_t lu32;
+typedef __attribute__((address_space(3))) char lchar;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lu128;
+// child references of the node a lane is working on: [lane][slot], written with one ds_write_b128 and read back by
+// slot.  Picking one of four registers by a per-lane index costs seven vector instructions (two tests, three selects),
+// four times per node; one v_and_or_b32 and a ds_read_b32 do the same and the LDS pipe has the room.
+__shared__ u32x4 s_child[64];
+
 struct StackRef {
-    uint32_t *lds;   // this lane's column, stride 64
-    uint32_t *spill; // this lane's column, stride spill_stride
+    uint32_t *spill;    // this lane's column, stride spill_stride
+    uint32_t sp0;       // Trav::sp of an empty stack (LDS address of s_stack + lane * 4)
+    uint32_t lds_limit; // sp0 of lane 0 + lds_entries * 256: a Trav::sp below it names an entry in LDS
+    uint32_t child16;   // LDS address of s_child[lane]
     int lds_entries;
     uint32_t spill_stride;
 };
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)(lchar *)p; }
+__device__ __forceinline__ void stack_ref_init(StackRef &K, uint32_t lane, uint32_t *spill, int lds_entries, uint32_t total_lanes) {
+    K.spill = spill + (size_t)blockIdx.x * 64u + lane;
+    K.sp0 = lds_addr(s_stack) + lane * 4u;
+    K.lds_limit = lds_addr(s_stack) + (uint32_t)lds_entries * 256u;
+    K.child16 = lds_addr(s_child) + lane * 16u;
+    K.lds_entries = lds_entries;
+    K.spill_stride = total_lanes;
+}
+__device__ __forceinline__ lu32 *stk_lds(uint32_t sp) { return (lu32 *)(uintptr_t)sp; }
 // The spill accesses are volatile so that hipcc cannot fold "LDS or global" into one flat_load / flat_store
 // (a flat access waits on both counters and is slower than ds_read even when it lands in LDS).
-__device__ __forceinline__ void stk_push(const StackRef &K, int &sp, uint32_t v) {
-    if (__builtin_expect(sp < K.lds_entries, 1))
-        K.lds[sp * 64] = v;
+__device__ __forceinline__ void stk_push(const StackRef &K, uint32_t &sp, uint32_t v) {
+    if (__builtin_expect(sp < K.lds_limit, 1))
+        *stk_lds(sp) = v;
     else
-        *(volatile gu32 *)(K.spill + (size_t)(sp - K.lds_entries) * K.spill_stride) = v;
-    sp++;
+        *(volatile gu32 *)(K.spill + (size_t)((sp - K.lds_limit) >> 8) * K.spill_stride) = v;
+    sp += 256u;
 }
-__device__ __forceinline__ uint32_t stk_pop(const StackRef &K, int &sp) {
-    sp--;
+__device__ __forceinline__ uint32_t stk_pop(const StackRef &K, uint32_t &sp) {
+    sp -= 256u;
     uint32_t v;
-    if (__builtin_expect(sp < K.lds_entries, 1))
-        v = K.lds[sp * 64];
+    if (__builtin_expect(sp < K.lds_limit, 1))
+        v = *stk_lds(sp);
     else
-        v = *(volatile gu32 *)(K.spill + (size_t)(sp - K.lds_entries) * K.spill_stride);
+        v = *(volatile gu32 *)(K.spill + (size_t)((sp - K.lds_limit) >> 8) * K.spill_stride);
     return v;
+}
+
+// slot of a child in its sort key: bits 3:2, so that key & 12 is the byte offset of its reference in s_child[lane]
+#define RT_KEY(TN, I) ((__float_as_uint(TN) & ~15u) | ((I) << 2))
+__device__ __forceinline__ uint32_t child_ref(uint32_t key, uint32_t child16) {
+    uint32_t a; // hipcc turns (key & 12) | child16 into an and and an add
+    asm("v_and_or_b32 %0, %1, 12, %2" : "=v"(a) : "v"(key), "v"(child16));
+    return *(lu32 *)(uintptr_t)a;
 }
 
 // sort the (up to four) hit children by entry distance, continue with the nearest, push the others far-first
@@ -661,24 +691,42 @@ __device__ __forceinline__ uint32_t stk_pop(const StackRef &K, int &sp) {
     RT_CSWAP(k1, k3)                                                                                                   \
     RT_CSWAP(k1, k2)                                                                                                   \
     if (k0 != 0xFFFFFFFFu) {                                                                                           \
-        T.cur = sel4(ch, k0 & 3u);                                                                                     \
+        const uint32_t lane16 = K.child16;                                                                             \
+        *(lu128 *)(uintptr_t)lane16 = u32x4{ch.x, ch.y, ch.z, ch.w};                                                   \
+        T.cur = child_ref(k0, lane16);                                                                                 \
         if (k1 != 0xFFFFFFFFu) {                                                                                       \
-            if (k2 != 0xFFFFFFFFu) {                                                                                   \
-                if (k3 != 0xFFFFFFFFu) stk_push(K, T.sp, sel4(ch, k3 & 3u));                                           \
-                stk_push(K, T.sp, sel4(ch, k2 & 3u));                                                                  \
+            const uint32_t c1 = child_ref(k1, lane16), c2 = child_ref(k2, lane16), c3 = child_ref(k3, lane16);         \
+            if (__builtin_expect(fast, 1)) { /* all three entries would be in LDS */                                   \
+                if (k2 != 0xFFFFFFFFu) {                                                                               \
+                    if (k3 != 0xFFFFFFFFu) {                                                                           \
+                        *stk_lds(T.sp) = c3;                                                                           \
+                        T.sp += 256u;                                                                                  \
+                    }                                                                                                  \
+                    *stk_lds(T.sp) = c2;                                                                               \
+                    T.sp += 256u;                                                                                      \
+                }                                                                                                      \
+                *stk_lds(T.sp) = c1;                                                                                   \
+                T.sp += 256u;                                                                                          \
+            } else {                                                                                                   \
+                if (k2 != 0xFFFFFFFFu) {                                                                               \
+                    if (k3 != 0xFFFFFFFFu) stk_push(K, T.sp, c3);                                                      \
+                    stk_push(K, T.sp, c2);                                                                             \
+                }                                                                                                      \
+                stk_push(K, T.sp, c1);                                                                                 \
             }                                                                                                          \
-            stk_push(K, T.sp, sel4(ch, k1 & 3u));                                                                      \
         }                                                                                                              \
         return;                                                                                                        \
     }
 
-__device__ __forceinline__ uint32_t pop_or_none(const StackRef &K, int &sp) { return sp == 0 ? RT_REF_NONE : stk_pop(K, sp); }
+__device__ __forceinline__ uint32_t pop_or_none(const StackRef &K, uint32_t &sp) { return sp == K.sp0 ? RT_REF_NONE : stk_pop(K, sp); }
 
 // one wide node: tests its four child boxes, sets T.cur to the nearest hit child (pushing the others) or to the
 // next stack entry (RT_REF_NONE when the stack is empty).
 // FMT 0: 128-byte float nodes (WideNode).  FMT 1: 64-byte quantized nodes (QuantNode).
 template <int FMT>
 __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const StackRef &K) {
+    // every stack entry this step can touch is in LDS (entries [e - 1, e + 2] for a stack of e): the common case
+    const bool fast = T.sp + 512u < K.lds_limit;
     {
         uint32_t k0, k1, k2, k3;
         if (FMT == 0) {
@@ -693,7 +741,7 @@ __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const S
                          fmaxf(__builtin_fmaf(nz.C, T.idz, T.noz), 0.001f));                                           \
         float tf = fminf(fminf(__builtin_fmaf(fx.C, T.idx, T.nox), __builtin_fmaf(fy.C, T.idy, T.noy)),                \
                          fminf(__builtin_fmaf(fz.C, T.idz, T.noz), T.best_t));                                         \
-        K_ = (tn <= tf) ? ((__float_as_uint(tn) & ~3u) | I) : 0xFFFFFFFFu;                                             \
+        K_ = (tn <= tf) ? RT_KEY(tn, I) : 0xFFFFFFFFu;                                                                 \
     }
             RT_SLAB(k0, x, 0u)
             RT_SLAB(k1, y, 1u)
@@ -709,9 +757,9 @@ __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const S
             RT_PIN4(qb);
             RT_PIN4(ch);
             // grid step per axis (a power of two) folded into the ray's reciprocal direction
-            const float sx = __uint_as_float((h.w & 0xFFu) << 23) * T.idx;
-            const float sy = __uint_as_float(((h.w >> 8) & 0xFFu) << 23) * T.idy;
-            const float sz = __uint_as_float(((h.w >> 16) & 0xFFu) << 23) * T.idz;
+            const float sx = __uint_as_float(h.w) * T.idx;
+            const float sy = __uint_as_float(qb.z) * T.idy;
+            const float sz = __uint_as_float(qb.w) * T.idz;
             const float ax = __builtin_fmaf(__uint_as_float(h.x), T.idx, T.nox);
             const float ay = __builtin_fmaf(__uint_as_float(h.y), T.idy, T.noy);
             const float az = __builtin_fmaf(__uint_as_float(h.z), T.idz, T.noz);
@@ -728,7 +776,7 @@ __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const S
                          fmaxf(__builtin_fmaf(RT_QB(nqz, SH), sz, az), 0.001f));                                       \
         float tf = fminf(fminf(__builtin_fmaf(RT_QB(fqx, SH), sx, ax), __builtin_fmaf(RT_QB(fqy, SH), sy, ay)),        \
                          fminf(__builtin_fmaf(RT_QB(fqz, SH), sz, az), T.best_t));                                     \
-        K_ = (tn <= tf) ? ((__float_as_uint(tn) & ~3u) | I) : 0xFFFFFFFFu;                                             \
+        K_ = (tn <= tf) ? RT_KEY(tn, I) : 0xFFFFFFFFu;                                                                 \
     }
             RT_SLABQ(k0, 0, 0u)
             RT_SLABQ(k1, 8, 1u)
@@ -739,7 +787,16 @@ __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const S
             RT_SORT_AND_PUSH()
         }
     }
-    T.cur = pop_or_none(K, T.sp);
+    if (__builtin_expect(fast, 1)) {
+        if (T.sp == K.sp0) {
+            T.cur = RT_REF_NONE;
+        } else {
+            T.sp -= 256u;
+            T.cur = *stk_lds(T.sp);
+        }
+    } else {
+        T.cur = pop_or_none(K, T.sp);
+    }
 }
 
 // one leaf: tests its primitives; min t, ties to the earlier DFS leaf (pbrt_engine.cu:421-438)
@@ -770,6 +827,10 @@ __device__ __forceinline__ bool trav_step(Trav &T, const KernelScene &S, const R
     return T.cur != RT_REF_NONE;
 }
 
+// __ballot() takes an int and compares it with zero in a vector register (v_cndmask + v_cmp per call); the builtin
+// takes the predicate where it already is, in a scalar mask
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // which XCD this wave runs on (HW_REG_XCC_ID, bits 3:0): used for L2 affinity only, never for correctness
@@ -792,7 +853,7 @@ __device__ __forceinline__ bool fetch_slot(unsigned int *band_counters, uint32_t
                                            bool need, uint32_t &slot, uint32_t rounds, uint32_t &round) {
     const uint32_t lane = lane_id();
     for (int guard = 0; guard < 64; guard++) {
-        const unsigned long long mask = __ballot(need);
+        const unsigned long long mask = ballot(need);
         if (mask == 0ull) break;
         const uint32_t avail = q.end - q.next;
         if (avail == 0u) {
@@ -876,10 +937,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                                                    float *ts) {
     const uint32_t lane = threadIdx.x;
     StackRef K;
-    K.lds = s_stack + lane;
-    K.spill = P.spill + (size_t)blockIdx.x * 64u + lane;
-    K.lds_entries = P.lds_entries;
-    K.spill_stride = P.total_lanes;
+    stack_ref_init(K, lane, P.spill, P.lds_entries, P.total_lanes);
     const uint32_t home = xcc_id();
     const uint32_t n_tiles = (uint32_t)F.n_local_tiles;
     SlotQueue q;
@@ -896,7 +954,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
     cur.o = mk(0, 0, 0);
     cur.d = mk(0, 0, 1);
     Trav T;
-    trav_begin(T, cur);
+    trav_begin(T, cur, K.sp0);
     uint32_t nr = 0;
     bool waiting = false;   // slot taken in a round > 0 whose record has not been published yet
     uint32_t slot_round = 0; // slot of the pixel in hand | round << 26 (slots < 2^26, rounds < 64)
@@ -916,7 +974,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
 #endif
         since_poll = 0;
         bool want_push = false;
-        RT_STAT(kStatShadeLanes, __popcll(__ballot(has_pixel && result_ready)));
+        RT_STAT(kStatShadeLanes, __popcll(ballot(has_pixel && result_ready)));
         if (has_pixel && result_ready) {
             result_ready = false;
             Hit h;
@@ -982,7 +1040,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
         {
             uint32_t slot = 0;
             const bool need = !has_pixel && !retired && !waiting;
-            RT_STAT(kStatFetchLanes, __popcll(__ballot(need)));
+            RT_STAT(kStatFetchLanes, __popcll(ballot(need)));
             uint32_t round = 0;
             const bool got = fetch_slot<64u>(P.band_counters, n_tiles, home, q, need, slot, rounds, round);
             if (need) {
@@ -1028,7 +1086,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                 }
             }
         }
-        RT_STAT(kStatPrimaryLanes, __popcll(__ballot(has_pixel && !tracing && need_primary)));
+        RT_STAT(kStatPrimaryLanes, __popcll(ballot(has_pixel && !tracing && need_primary)));
         if (has_pixel && !tracing) {
             if (need_primary) {
                 cur = primary_ray(F.cam, (int)(pij & 0xFFFFu), (int)(pij >> 16), F.nx, F.ny, g);
@@ -1045,12 +1103,12 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                 }
             }
 #endif
-            trav_begin(T, cur);
+            trav_begin(T, cur, K.sp0);
             tracing = true;
             nr++;
         }
-        if (__ballot(!retired) == 0ull) break;
-        if (ring_on && __ballot(tracing) == 0ull) {
+        if (ballot(!retired) == 0ull) break;
+        if (ring_on && ballot(tracing) == 0ull) {
             // every live lane waits for a ring item: nothing to do but poll.  Sleep between polls (127 x 64 clocks,
             // ~3.5 us) so that the waiting wave leaves the SIMD's issue slots to the waves that still produce.
             RT_STAT(kStatSpinPolls, 1);
@@ -1063,15 +1121,15 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
 #endif
         // ---------------- traversal phase
         for (;;) {
-            const unsigned long long act = __ballot(tracing);
+            const unsigned long long act = ballot(tracing);
             if (act == 0ull) break;
             // lanes the refill phase could do something for (a lane that waits for a ring item is not one)
-            if ((int)__popcll(act) < P.threshold && __ballot(!tracing && !retired && !waiting) != 0ull) break;
-            if (ring_on && ++since_poll > 8 && __ballot(waiting) != 0ull) break; // poll now and then
+            if ((int)__popcll(act) < P.threshold && ballot(!tracing && !retired && !waiting) != 0ull) break;
+            if (ring_on && ++since_poll > 8 && ballot(waiting) != 0ull) break; // poll now and then
             RT_STAT(kStatIters, 1);
             RT_STAT(kStatIdleLanes, 64 - __popcll(act));
-            RT_STAT(kStatRetiredLanes, __popcll(__ballot(retired && !tracing)));
-            RT_STAT(kStatWaitLanes, __popcll(__ballot(waiting)));
+            RT_STAT(kStatRetiredLanes, __popcll(ballot(retired && !tracing)));
+            RT_STAT(kStatWaitLanes, __popcll(ballot(waiting)));
             if (SPEC == 0) {
                 if (tracing) {
                     if (!trav_step<FMT>(T, S, cur, K)) {
@@ -1082,15 +1140,15 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
             } else {
 #ifdef RT_TRAV_STATS
                 {
-                    const int nl = __popcll(__ballot(tracing && !(T.cur & kLeafBit)));
+                    const int nl = __popcll(ballot(tracing && !(T.cur & kLeafBit)));
                     RT_STAT(kStatNodeLanes, nl);
                     RT_STAT(kStatNodeIters, nl != 0);
                     for (int bb = 0; bb < 8; bb++) { // divergence per bounce: lanes of each bounce depth testing a node
-                        const int nb = __popcll(__ballot(tracing && !(T.cur & kLeafBit) && (bounce < 7 ? bounce : 7) == bb));
+                        const int nb = __popcll(ballot(tracing && !(T.cur & kLeafBit) && (bounce < 7 ? bounce : 7) == bb));
                         RT_STAT(kStatNodeLanesByBounce + bb, nb);
                         RT_STAT(kStatItersWithBounce + bb, nb != 0);
                     }
-                    RT_STAT(kStatStalledLanes, __popcll(__ballot(tracing && T.cur != RT_REF_NONE && (T.cur & kLeafBit) && T.pend != RT_REF_NONE)));
+                    RT_STAT(kStatStalledLanes, __popcll(ballot(tracing && T.cur != RT_REF_NONE && (T.cur & kLeafBit) && T.pend != RT_REF_NONE)));
                 }
 #endif
                 if (tracing && !(T.cur & kLeafBit)) node_step<FMT>(T, S, K);
@@ -1100,9 +1158,9 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                     T.cur = pop_or_none(K, T.sp);
                 }
                 const bool want_leaf = tracing && T.pend != RT_REF_NONE;
-                const unsigned long long leaf_mask = __ballot(want_leaf);
+                const unsigned long long leaf_mask = ballot(want_leaf);
                 if (leaf_mask != 0ull) {
-                    const unsigned long long node_mask = __ballot(tracing && !(T.cur & kLeafBit));
+                    const unsigned long long node_mask = ballot(tracing && !(T.cur & kLeafBit));
                     if (node_mask == 0ull || (int)__popcll(leaf_mask) >= P.leaf_batch) {
                         RT_STAT(kStatLeafFires, 1);
                         RT_STAT(kStatLeafLanes, __popcll(leaf_mask));
@@ -1154,10 +1212,7 @@ template <int FMT>
 __global__ void __launch_bounds__(64, 6) k_trace_queue(KernelScene S, PersistArgs P, QueueArgs Q) {
     const uint32_t lane = threadIdx.x;
     StackRef K;
-    K.lds = s_stack + lane;
-    K.spill = P.spill + (size_t)blockIdx.x * 64u + lane;
-    K.lds_entries = P.lds_entries;
-    K.spill_stride = P.total_lanes;
+    stack_ref_init(K, lane, P.spill, P.lds_entries, P.total_lanes);
     uint32_t q_next = 0, q_end = 0; // wave-uniform: this wave's run of ray indices
     bool exhausted = false;          // wave-uniform: the counter has passed n
     bool tracing = false;
@@ -1166,11 +1221,11 @@ __global__ void __launch_bounds__(64, 6) k_trace_queue(KernelScene S, PersistArg
     cur.o = mk(0, 0, 0);
     cur.d = mk(0, 0, 1);
     Trav T;
-    trav_begin(T, cur);
+    trav_begin(T, cur, K.sp0);
     for (;;) {
         // ---- hand out rays to the idle lanes
         for (int guard = 0; guard < 4; guard++) {
-            const unsigned long long idle = __ballot(!tracing);
+            const unsigned long long idle = ballot(!tracing);
             if (idle == 0ull || exhausted) break;
             if (q_next == q_end) {
                 uint32_t base = 0;
@@ -1191,18 +1246,18 @@ __global__ void __launch_bounds__(64, 6) k_trace_queue(KernelScene S, PersistArg
                 const float2 a = r[0], b = r[1], c = r[2];
                 cur.o = mk(a.x, a.y, b.x);
                 cur.d = mk(b.y, c.x, c.y);
-                trav_begin(T, cur);
+                trav_begin(T, cur, K.sp0);
                 tracing = true;
                 nr++;
             }
             const uint32_t cnt = (uint32_t)__popcll(idle);
             q_next += cnt < avail ? cnt : avail;
         }
-        const unsigned long long act0 = __ballot(tracing);
+        const unsigned long long act0 = ballot(tracing);
         if (act0 == 0ull) break; // nothing in flight and nothing left to take
         // ---- traverse until enough lanes are free to make a refill worth its few instructions
         for (;;) {
-            const unsigned long long act = __ballot(tracing);
+            const unsigned long long act = ballot(tracing);
             if (act == 0ull) break;
             if (!exhausted && (int)__popcll(act) < P.threshold) break;
             if (tracing && !(T.cur & kLeafBit)) node_step<FMT>(T, S, K);
@@ -1211,9 +1266,9 @@ __global__ void __launch_bounds__(64, 6) k_trace_queue(KernelScene S, PersistArg
                 T.cur = pop_or_none(K, T.sp);
             }
             const bool want_leaf = tracing && T.pend != RT_REF_NONE;
-            const unsigned long long leaf_mask = __ballot(want_leaf);
+            const unsigned long long leaf_mask = ballot(want_leaf);
             if (leaf_mask != 0ull) {
-                const unsigned long long node_mask = __ballot(tracing && !(T.cur & kLeafBit));
+                const unsigned long long node_mask = ballot(tracing && !(T.cur & kLeafBit));
                 if (node_mask == 0ull || (int)__popcll(leaf_mask) >= P.leaf_batch) {
                     if (want_leaf) {
                         leaf_test(T, S, cur, T.pend);
@@ -1291,10 +1346,7 @@ template <int FMT, int OCC>
 __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, PersistArgs P, DualArgs D, float *fb) {
     const uint32_t lane = threadIdx.x;
     StackRef K;
-    K.lds = s_stack + lane;
-    K.spill = P.spill + (size_t)blockIdx.x * 64u + lane;
-    K.lds_entries = P.lds_entries;
-    K.spill_stride = P.total_lanes;
+    stack_ref_init(K, lane, P.spill, P.lds_entries, P.total_lanes);
     const uint32_t home = xcc_id();
     const uint32_t n_tiles = (uint32_t)F.n_local_tiles;
     SlotQueue q;
@@ -1314,7 +1366,7 @@ __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, 
     int t_status = RT_T_EMPTY, w_status = RT_W_EMPTY;
     bool retired = false;
     Trav T;
-    trav_begin(T, cur);
+    trav_begin(T, cur, K.sp0);
     T.cur = RT_REF_NONE;
     uint32_t nr = 0;
 #ifdef RT_TRAV_STATS
@@ -1324,7 +1376,7 @@ __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, 
     for (;;) {
         // ---------------- shading phase: slot W
         RT_STAT(kStatRefills, 1);
-        RT_STAT(kStatShadeLanes, __popcll(__ballot(w_status == RT_W_DONE)));
+        RT_STAT(kStatShadeLanes, __popcll(ballot(w_status == RT_W_DONE)));
         bool need_primary = false;
         if (w_status == RT_W_DONE) {
             Hit h;
@@ -1358,7 +1410,7 @@ __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, 
         {
             uint32_t slot = 0;
             const bool need = w_status == RT_W_EMPTY && !retired;
-            RT_STAT(kStatFetchLanes, __popcll(__ballot(need)));
+            RT_STAT(kStatFetchLanes, __popcll(ballot(need)));
             uint32_t round = 0;
             const bool got = fetch_slot<64u>(P.band_counters, n_tiles, home, q, need, slot, 1u, round);
             if (need) {
@@ -1379,23 +1431,23 @@ __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, 
                 }
             }
         }
-        RT_STAT(kStatPrimaryLanes, __popcll(__ballot(need_primary)));
+        RT_STAT(kStatPrimaryLanes, __popcll(ballot(need_primary)));
         if (need_primary) {
             wr = primary_ray(F.cam, (int)(pw.pij & 0xFFFFu), (int)(pw.pij >> 16), F.nx, F.ny, pw.g);
             pw.thr = mk(1.0f, 1.0f, 1.0f);
             pw.bounce = 0;
             w_status = RT_W_READY;
         }
-        if (__ballot(!(retired && t_status == RT_T_EMPTY && w_status == RT_W_EMPTY)) == 0ull) break;
+        if (ballot(!(retired && t_status == RT_T_EMPTY && w_status == RT_W_EMPTY)) == 0ull) break;
 
         // ---------------- traversal phase: slot T
         for (;;) {
-            unsigned long long act = __ballot(t_status == RT_T_TRACING);
+            unsigned long long act = ballot(t_status == RT_T_TRACING);
             {
                 // T has nothing to traverse and W has a ray, or T holds a result and W is free to take it
                 const bool want = t_status != RT_T_TRACING &&
                                   (w_status == RT_W_READY || (t_status == RT_T_DONE && w_status == RT_W_EMPTY));
-                const unsigned long long sw = __ballot(want);
+                const unsigned long long sw = ballot(want);
                 if (sw != 0ull && ((int)__popcll(sw) >= D.swap_batch || act == 0ull)) {
                     if (want) {
                         vswap(pt, pw);
@@ -1405,7 +1457,7 @@ __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, 
                         wrank = T.best_rank;
                         const int new_w = t_status == RT_T_DONE ? RT_W_DONE : RT_W_EMPTY;
                         if (w_status == RT_W_READY) {
-                            trav_begin(T, cur);
+                            trav_begin(T, cur, K.sp0);
                             t_status = RT_T_TRACING;
                             nr++;
                         } else {
@@ -1413,25 +1465,25 @@ __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, 
                         }
                         w_status = new_w;
                     }
-                    act = __ballot(t_status == RT_T_TRACING);
+                    act = ballot(t_status == RT_T_TRACING);
                 }
             }
             if (act == 0ull) break;
             {
-                const unsigned long long work = __ballot(w_status == RT_W_DONE || (w_status == RT_W_EMPTY && !retired));
+                const unsigned long long work = ballot(w_status == RT_W_DONE || (w_status == RT_W_EMPTY && !retired));
                 if ((int)__popcll(work) >= D.shade_batch) break;
                 if ((int)__popcll(act) < P.threshold && work != 0ull) break;
             }
             RT_STAT(kStatIters, 1);
             RT_STAT(kStatIdleLanes, 64 - __popcll(act));
-            RT_STAT(kStatRetiredLanes, __popcll(__ballot(retired && t_status == RT_T_EMPTY && w_status == RT_W_EMPTY)));
+            RT_STAT(kStatRetiredLanes, __popcll(ballot(retired && t_status == RT_T_EMPTY && w_status == RT_W_EMPTY)));
             const bool tracing = t_status == RT_T_TRACING;
 #ifdef RT_TRAV_STATS
             {
-                const int nl = __popcll(__ballot(tracing && !(T.cur & kLeafBit)));
+                const int nl = __popcll(ballot(tracing && !(T.cur & kLeafBit)));
                 RT_STAT(kStatNodeLanes, nl);
                 RT_STAT(kStatNodeIters, nl != 0);
-                RT_STAT(kStatStalledLanes, __popcll(__ballot(tracing && T.cur != RT_REF_NONE && (T.cur & kLeafBit) && T.pend != RT_REF_NONE)));
+                RT_STAT(kStatStalledLanes, __popcll(ballot(tracing && T.cur != RT_REF_NONE && (T.cur & kLeafBit) && T.pend != RT_REF_NONE)));
             }
 #endif
             if (tracing && !(T.cur & kLeafBit)) node_step<FMT>(T, S, K);
@@ -1440,9 +1492,9 @@ __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, 
                 T.cur = pop_or_none(K, T.sp);
             }
             const bool want_leaf = tracing && T.pend != RT_REF_NONE;
-            const unsigned long long leaf_mask = __ballot(want_leaf);
+            const unsigned long long leaf_mask = ballot(want_leaf);
             if (leaf_mask != 0ull) {
-                const unsigned long long node_mask = __ballot(tracing && !(T.cur & kLeafBit));
+                const unsigned long long node_mask = ballot(tracing && !(T.cur & kLeafBit));
                 if (node_mask == 0ull || (int)__popcll(leaf_mask) >= P.leaf_batch) {
                     RT_STAT(kStatLeafFires, 1);
                     RT_STAT(kStatLeafLanes, __popcll(leaf_mask));

@@ -20,15 +20,16 @@ static_assert(sizeof(WideNode) == 128, "WideNode must be one 128-byte line");
 // Child boxes are stored as 8-bit offsets from the node's own origin on a power-of-two grid per axis
 // (conservative: lo rounded down, hi rounded up), so a node visit moves 4 x 16 bytes through the
 // vector memory path instead of 7 x 16:
-//   16 B: origin x, y, z (float), exps = ex | ey << 8 | ez << 16  (biased binary32 exponents of the grid step)
+//   16 B: origin x, y, z (float), grid step of x (float, a power of two)
 //   16 B: qlo_x[4], qhi_x[4], qlo_y[4], qhi_y[4]   (one byte per child, child c in byte c)
-//   16 B: qlo_z[4], qhi_z[4], 8 bytes unused
+//   16 B: qlo_z[4], qhi_z[4], grid step of y, grid step of z (floats: the kernel multiplies, it decodes nothing)
 //   16 B: child[4]   (same encoding as WideNode::child)
 struct QuantNode {
     float origin[3];
-    uint32_t exps;
+    float step_x;
     uint32_t qx_lo, qx_hi, qy_lo, qy_hi;
-    uint32_t qz_lo, qz_hi, pad0, pad1;
+    uint32_t qz_lo, qz_hi;
+    float step_y, step_z;
     uint32_t child[4];
 };
 static_assert(sizeof(QuantNode) == 64, "QuantNode must be 64 bytes");

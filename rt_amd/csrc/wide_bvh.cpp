@@ -323,7 +323,7 @@ bool build_wide_bvh(const rt_triangle148 *tris, int n, const rt_bvh_node32 *node
             qlo[a] = plo;
             qhi[a] = phi;
             q.origin[a] = org;
-            q.exps |= (uint32_t)(e + 127) << (8 * a);
+            (a == 0 ? q.step_x : a == 1 ? q.step_y : q.step_z) = (float)step; // 2^e, e in [-100, 127]: exact
         }
         q.qx_lo = qlo[0]; q.qx_hi = qhi[0];
         q.qy_lo = qlo[1]; q.qy_hi = qhi[1];

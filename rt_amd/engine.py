@@ -152,7 +152,7 @@ def tile_owner(nx: int, ny: int, world: int) -> np.ndarray:
 
 
 WIDE_DTYPE = np.dtype([("plane", "<f4", (6, 4)), ("child", "<u4", 4), ("aux", "<u4", 4)])
-QUANT_DTYPE = np.dtype([("origin", "<f4", 3), ("exps", "<u4"), ("q", "<u4", 6), ("pad", "<u4", 2), ("child", "<u4", 4)])
+QUANT_DTYPE = np.dtype([("origin", "<f4", 3), ("step_x", "<f4"), ("q", "<u4", 6), ("step_yz", "<f4", 2), ("child", "<u4", 4)])
 PRIM_DTYPE = np.dtype([("a", "<f4", 4), ("b", "<f4", 4), ("e2z", "<f4"), ("shape", "<i4"), ("orig", "<i4"), ("ref_rank", "<i4")])
 
 

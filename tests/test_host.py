@@ -203,7 +203,8 @@ def test_quantized_nodes_are_conservative():
         assert (qn["child"] == wide["child"]).all()
         valid = wide["child"] != 0xFFFFFFFF
         for a in range(3):
-            step = np.ldexp(1.0, ((qn["exps"] >> (8 * a)) & 0xFF).astype(np.int64) - 127)
+            step = (qn["step_x"] if a == 0 else qn["step_yz"][:, a - 1]).astype(np.float64)
+            assert (np.frexp(step)[0] == 0.5).all()  # powers of two
             for s in range(4):
                 lo = qn["origin"][:, a].astype(np.float64) + ((qn["q"][:, 2 * a] >> (8 * s)) & 0xFF) * step
                 hi = qn["origin"][:, a].astype(np.float64) + ((qn["q"][:, 2 * a + 1] >> (8 * s)) & 0xFF) * step
