@@ -955,6 +955,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
     cur.d = mk(0, 0, 1);
     Trav T;
     trav_begin(T, cur, K.sp0);
+    T.cur = RT_REF_NONE; // invariant: a lane that is not tracing has T.cur == T.pend == RT_REF_NONE
     uint32_t nr = 0;
     bool waiting = false;   // slot taken in a round > 0 whose record has not been published yet
     uint32_t slot_round = 0; // slot of the pixel in hand | round << 26 (slots < 2^26, rounds < 64)
@@ -1120,8 +1121,11 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
         RT_STAT(kStatRefillClocks, clk1 - clk0);
 #endif
         // ---------------- traversal phase
+        // Ballots are taken from comparisons of T.cur / T.pend made where they are needed: a ballot of a bool that
+        // was set in another block costs hipcc a v_cndmask and a v_cmp each time.  The invariant above makes
+        // "tracing &&" redundant in them.
+        unsigned long long act = ballot(tracing);
         for (;;) {
-            const unsigned long long act = ballot(tracing);
             if (act == 0ull) break;
             // lanes the refill phase could do something for (a lane that waits for a ring item is not one)
             if ((int)__popcll(act) < P.threshold && ballot(!tracing && !retired && !waiting) != 0ull) break;
@@ -1137,6 +1141,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                         result_ready = true;
                     }
                 }
+                act = ballot(tracing);
             } else {
 #ifdef RT_TRAV_STATS
                 {
@@ -1151,16 +1156,23 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                     RT_STAT(kStatStalledLanes, __popcll(ballot(tracing && T.cur != RT_REF_NONE && (T.cur & kLeafBit) && T.pend != RT_REF_NONE)));
                 }
 #endif
-                if (tracing && !(T.cur & kLeafBit)) node_step<FMT>(T, S, K);
+#ifdef RT_TRAV_STATS
+                const unsigned long long clk_n0 = __builtin_readcyclecounter();
+#endif
+                if (!(T.cur & kLeafBit)) node_step<FMT>(T, S, K);
+#ifdef RT_TRAV_STATS
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the step's stack reads have come back
+                RT_STAT(kStatNodeClocks, __builtin_readcyclecounter() - clk_n0);
+#endif
                 // park a reached leaf in the pending slot and go on with the next stack entry
-                if (tracing && T.pend == RT_REF_NONE && T.cur != RT_REF_NONE && (T.cur & kLeafBit)) {
+                if (T.pend == RT_REF_NONE && T.cur != RT_REF_NONE && (T.cur & kLeafBit)) {
                     T.pend = T.cur;
                     T.cur = pop_or_none(K, T.sp);
                 }
-                const bool want_leaf = tracing && T.pend != RT_REF_NONE;
+                const bool want_leaf = T.pend != RT_REF_NONE;
                 const unsigned long long leaf_mask = ballot(want_leaf);
                 if (leaf_mask != 0ull) {
-                    const unsigned long long node_mask = ballot(tracing && !(T.cur & kLeafBit));
+                    const unsigned long long node_mask = ballot(!(T.cur & kLeafBit));
                     if (node_mask == 0ull || (int)__popcll(leaf_mask) >= P.leaf_batch) {
                         RT_STAT(kStatLeafFires, 1);
                         RT_STAT(kStatLeafLanes, __popcll(leaf_mask));
@@ -1171,16 +1183,24 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                             RT_STAT(kStatLeafPrims, np);
                         }
 #endif
+#ifdef RT_TRAV_STATS
+                        const unsigned long long clk_l0 = __builtin_readcyclecounter();
+#endif
                         if (want_leaf) {
                             leaf_test(T, S, cur, T.pend);
                             T.pend = RT_REF_NONE;
                         }
+#ifdef RT_TRAV_STATS
+                        RT_STAT(kStatLeafClocks, __builtin_readcyclecounter() - clk_l0);
+#endif
                     }
                 }
-                if (tracing && T.cur == RT_REF_NONE && T.pend == RT_REF_NONE) {
+                const bool fin = (T.cur & T.pend) == RT_REF_NONE;
+                if (tracing && fin) {
                     tracing = false;
                     result_ready = true;
                 }
+                act = ballot(!fin);
             }
         }
 #ifdef RT_TRAV_STATS
