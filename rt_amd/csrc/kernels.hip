@@ -69,10 +69,17 @@ struct Hit {
 // Primitive test.  Triangle: Triangle::hit, include/RT/triangle.h:136-179 (Moeller-Trumbore, no
 // determinant epsilon, two-sided).  Sphere: triangle.h:180-213 (near root only; the "second root"
 // repeats the minus sign).  t interval is the reference's fixed (0.001, FLT_MAX).
-__device__ __forceinline__ bool prim_test(const float4 *__restrict__ prims, uint32_t rank, const Ray &r, float &t_out,
-                                          int &ref_rank) {
+struct PrimRegs {
+    float4 A, B, C;
+};
+__device__ __forceinline__ PrimRegs prim_load(const float4 *__restrict__ prims, uint32_t rank) {
     const float4 *p = prims + 3 * (size_t)rank;
-    float4 A = p[0], B = p[1], C = p[2];
+    PrimRegs R;
+    R.A = p[0], R.B = p[1], R.C = p[2];
+    return R;
+}
+__device__ __forceinline__ bool prim_test(const PrimRegs &R, const Ray &r, float &t_out, int &ref_rank) {
+    const float4 A = R.A, B = R.B, C = R.C;
     ref_rank = __float_as_int(C.w);
     if (__float_as_int(C.y) == 0) {
         V3 v0 = mk(A.x, A.y, A.z), e1 = mk(A.w, B.x, B.y), e2 = mk(B.z, B.w, C.x);
@@ -114,6 +121,11 @@ __device__ __forceinline__ bool better_hit(const float4 *__restrict__ prims, flo
     if (t < best_t) return true;
     if (t == best_t && best_idx != RT_NO_HIT) return ref_rank < __float_as_int(prims[3 * (size_t)best_idx + 2].w);
     return false;
+}
+
+__device__ __forceinline__ bool prim_test(const float4 *__restrict__ prims, uint32_t rank, const Ray &r, float &t_out,
+                                          int &ref_rank) {
+    return prim_test(prim_load(prims, rank), r, t_out, ref_rank);
 }
 
 __device__ __forceinline__ float safe_inv(float d) {
@@ -750,7 +762,9 @@ __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const S
 #undef RT_SLAB
             RT_SORT_AND_PUSH()
         } else {
-            const uint4 *n = S.qnodes + 4 * (size_t)T.cur;
+            // byte offset in 32 bits (rt_abi.cpp refuses more than 2^26 wide nodes): one shift and the scalar-base form
+            // of global_load instead of a 64-bit shift and a 64-bit add
+            const uint4 *n = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(S.qnodes) + (size_t)(uint32_t)(T.cur << 6));
             uint4 h = n[0], qa = n[1], qb = n[2], ch = n[3];
             RT_PIN4(h);
             RT_PIN4(qa);
@@ -803,6 +817,8 @@ __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const S
 __device__ __forceinline__ void leaf_test(Trav &T, const KernelScene &S, const Ray &r, uint32_t ref) {
     const uint32_t start = ref & kLeafStartMask;
     const uint32_t cnt = ((ref >> 28) & 7u) + 1u;
+    // (loading two primitives per trip before testing the first hides the second round trip of a two-primitive leaf,
+    // and costs 26 more spilled registers in the refill phase: 48.4 vs 48.2 ms, dropped)
     for (uint32_t i = 0; i < cnt; i++) {
         float t;
         int rr;
@@ -956,7 +972,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
     Trav T;
     trav_begin(T, cur, K.sp0);
     T.cur = RT_REF_NONE; // invariant: a lane that is not tracing has T.cur == T.pend == RT_REF_NONE
-    uint32_t nr = 0;
+    uint32_t nr = 0; // rays started by this wave: wave-uniform, lives in a scalar register
     bool waiting = false;   // slot taken in a round > 0 whose record has not been published yet
     uint32_t slot_round = 0; // slot of the pixel in hand | round << 26 (slots < 2^26, rounds < 64)
     int yield_k = 0;        // sample count at which it is handed on (ns: never)

@@ -168,6 +168,8 @@ int upload_scene(rt_ctx *c) {
                             c->box_mode, c->topology, c->wide, err))
         return fail(c, RT_E_ARG, "wide BVH: " + err);
     if ((size_t)c->wide.stack_entries * 64 * 4 > 64 * 1024) return fail(c, RT_E_LIMIT, "tree too deep for the LDS stack");
+    if (c->wide.qnodes.size() > ((size_t)1 << 26)) // the kernels address quantised nodes by a 32-bit byte offset
+        return fail(c, RT_E_LIMIT, "more than 2^26 wide nodes");
     free_scene(c);
     size_t nb = c->wide.nodes.size() * sizeof(WideNode), pb = c->wide.prims.size() * sizeof(DevPrim),
            sb = c->wide.shade.size() * sizeof(DevShade);
