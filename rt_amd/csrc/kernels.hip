@@ -648,7 +648,9 @@ typedef __attribute__((address_space(3))) u32x4 lu128;
 // child references of the node a lane is working on: [lane][slot], written with one ds_write_b128 and read back by
 // slot.  Picking one of four registers by a per-lane index costs seven vector instructions (two tests, three selects),
 // four times per node; one v_and_or_b32 and a ds_read_b32 do the same and the LDS pipe has the room.
-__shared__ u32x4 s_child[64];
+// The same kilobyte is the first four of the seven fields of the leaf exchange ([field][slot], see leaf_fire): the two
+// uses never overlap in time.
+__shared__ u32x4 s_child[7 * 16];
 
 struct StackRef {
     uint32_t *spill;    // this lane's column, stride spill_stride
@@ -831,6 +833,98 @@ __device__ __forceinline__ void leaf_test(Trav &T, const KernelScene &S, const R
     }
 }
 
+// __ballot() takes an int and compares it with zero in a vector register (v_cndmask + v_cmp per call); the builtin
+// takes the predicate where it already is, in a scalar mask
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+__device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Speculative traversal's leaf step for the whole wave.  A leaf holds two primitives as a rule and the step runs with
+// about 20 of 64 lanes, so the second primitive of a lane's leaf is handed to a lane that has no leaf to test: the
+// owner writes its ray and the primitive's index to LDS slot `rank among owners`, the helper with the same rank
+// among the free lanes reads it, every lane runs ONE primitive test (owners their first primitive, helpers the
+// borrowed one), helpers write (t, reference rank) back and owners merge it after their own result -- the order the
+// one-lane loop had, so the result is the same.  The primitive test is ~75 vector instructions; the exchange is
+// LDS traffic and ~25.  Owners without a helper, and primitives beyond the second, take the loop.
+// Must be called by all 64 lanes.  xchg = LDS address of s_child (the leaf exchange's fields).
+__device__ __forceinline__ void leaf_fire(Trav &T, const KernelScene &S, const Ray &cur, bool want_leaf, uint32_t xchg) {
+    const uint32_t ref = T.pend;
+    const uint32_t start = ref & kLeafStartMask;
+    const uint32_t cnt = want_leaf ? ((ref >> 28) & 7u) + 1u : 0u;
+    const bool two = cnt >= 2u;
+    const unsigned long long own_m = ballot(two), free_m = ballot(!want_leaf);
+    const uint32_t n_own = (uint32_t)__popcll(own_m), n_free = (uint32_t)__popcll(free_m);
+    const uint32_t pairs = n_own < n_free ? n_own : n_free; // wave-uniform
+    const uint32_t rank = mbcnt64(two ? own_m : free_m);
+    const bool exporting = two && rank < pairs, helping = !want_leaf && rank < pairs;
+    const uint32_t slot = xchg + rank * 4u;
+    Ray lr = cur;
+    uint32_t lp = start;
+    if (pairs != 0u) {
+        if (exporting) {
+            *(lu32 *)(uintptr_t)(slot + 0u * 256u) = __float_as_uint(cur.o.x);
+            *(lu32 *)(uintptr_t)(slot + 1u * 256u) = __float_as_uint(cur.o.y);
+            *(lu32 *)(uintptr_t)(slot + 2u * 256u) = __float_as_uint(cur.o.z);
+            *(lu32 *)(uintptr_t)(slot + 3u * 256u) = __float_as_uint(cur.d.x);
+            *(lu32 *)(uintptr_t)(slot + 4u * 256u) = __float_as_uint(cur.d.y);
+            *(lu32 *)(uintptr_t)(slot + 5u * 256u) = __float_as_uint(cur.d.z);
+            *(lu32 *)(uintptr_t)(slot + 6u * 256u) = start + 1u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (helping) {
+            lr.o.x = __uint_as_float(*(lu32 *)(uintptr_t)(slot + 0u * 256u));
+            lr.o.y = __uint_as_float(*(lu32 *)(uintptr_t)(slot + 1u * 256u));
+            lr.o.z = __uint_as_float(*(lu32 *)(uintptr_t)(slot + 2u * 256u));
+            lr.d.x = __uint_as_float(*(lu32 *)(uintptr_t)(slot + 3u * 256u));
+            lr.d.y = __uint_as_float(*(lu32 *)(uintptr_t)(slot + 4u * 256u));
+            lr.d.z = __uint_as_float(*(lu32 *)(uintptr_t)(slot + 5u * 256u));
+            lp = *(lu32 *)(uintptr_t)(slot + 6u * 256u);
+        }
+    }
+    float t = FLT_MAX;
+    int rr = 0;
+    bool hit = false;
+    if (want_leaf || helping) hit = prim_test(S.prims, lp, lr, t, rr);
+    if (pairs != 0u) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (helping) { // a hit has t < FLT_MAX (prim_test): FLT_MAX says "missed"
+            *(lu32 *)(uintptr_t)(slot + 0u * 256u) = __float_as_uint(hit ? t : FLT_MAX);
+            *(lu32 *)(uintptr_t)(slot + 1u * 256u) = (uint32_t)rr;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (want_leaf) {
+        if (hit && better_hit(S.prims, t, rr, T.best_t, T.best_rank)) {
+            T.best_t = t;
+            T.best_rank = (int)start;
+        }
+        uint32_t i = 1u;
+        if (exporting) {
+            const float t1 = __uint_as_float(*(lu32 *)(uintptr_t)(slot + 0u * 256u));
+            const int rr1 = (int)*(lu32 *)(uintptr_t)(slot + 1u * 256u);
+            if (t1 < FLT_MAX && better_hit(S.prims, t1, rr1, T.best_t, T.best_rank)) {
+                T.best_t = t1;
+                T.best_rank = (int)(start + 1u);
+            }
+            i = 2u;
+        }
+        for (; i < cnt; i++) {
+            if (prim_test(S.prims, start + i, cur, t, rr)) {
+                if (better_hit(S.prims, t, rr, T.best_t, T.best_rank)) {
+                    T.best_t = t;
+                    T.best_rank = (int)(start + i);
+                }
+            }
+        }
+        T.pend = RT_REF_NONE;
+    }
+}
+
 // one traversal step: one wide node, or one leaf.  returns false when the ray is finished.
 template <int FMT>
 __device__ __forceinline__ bool trav_step(Trav &T, const KernelScene &S, const Ray &r, const StackRef &K) {
@@ -842,10 +936,6 @@ __device__ __forceinline__ bool trav_step(Trav &T, const KernelScene &S, const R
     }
     return T.cur != RT_REF_NONE;
 }
-
-// __ballot() takes an int and compares it with zero in a vector register (v_cndmask + v_cmp per call); the builtin
-// takes the predicate where it already is, in a scalar mask
-__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -1202,10 +1292,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
 #ifdef RT_TRAV_STATS
                         const unsigned long long clk_l0 = __builtin_readcyclecounter();
 #endif
-                        if (want_leaf) {
-                            leaf_test(T, S, cur, T.pend);
-                            T.pend = RT_REF_NONE;
-                        }
+                        leaf_fire(T, S, cur, want_leaf, lds_addr(s_child));
 #ifdef RT_TRAV_STATS
                         RT_STAT(kStatLeafClocks, __builtin_readcyclecounter() - clk_l0);
 #endif
