@@ -153,7 +153,8 @@ enum {
     RT_OPT_SEED_SALT = 18,       /* added to the per-pixel seed 1995 + pixel_index (default 0 = the reference's streams) */
     RT_OPT_RAW_SUM = 19,         /* 1: the frame holds per-pixel SUMS of the (per-sample clamped) samples instead of the
                                     clamped mean, so that ranks' frames can be added and divided by the total count */
-    RT_OPT_QUEUE_THRESHOLD = 20  /* rt_trace_rays*: a lane takes its next ray when fewer than this many of 64 still traverse */
+    RT_OPT_QUEUE_THRESHOLD = 20, /* rt_trace_rays*: a lane takes its next ray when fewer than this many of 64 still traverse */
+    RT_OPT_QUEUE_WAVES = 21      /* rt_trace_rays*: most persistent waves per CU, 1..32 (default 24; a short array gets fewer) */
 };
 int rt_set_option(rt_ctx *ctx, int option, int64_t value);
 int rt_get_option(rt_ctx *ctx, int option, int64_t *value);

@@ -1392,12 +1392,8 @@ __global__ void __launch_bounds__(64, 6) k_trace_queue(KernelScene S, PersistArg
             const unsigned long long leaf_mask = ballot(want_leaf);
             if (leaf_mask != 0ull) {
                 const unsigned long long node_mask = ballot(tracing && !(T.cur & kLeafBit));
-                if (node_mask == 0ull || (int)__popcll(leaf_mask) >= P.leaf_batch) {
-                    if (want_leaf) {
-                        leaf_test(T, S, cur, T.pend);
-                        T.pend = RT_REF_NONE;
-                    }
-                }
+                if (node_mask == 0ull || (int)__popcll(leaf_mask) >= P.leaf_batch)
+                    leaf_fire(T, S, cur, want_leaf, lds_addr(s_child));
             }
             if (tracing && T.cur == RT_REF_NONE && T.pend == RT_REF_NONE) {
                 tracing = false;

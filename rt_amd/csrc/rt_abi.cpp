@@ -38,6 +38,7 @@ struct rt_ctx {
     unsigned long long seed_salt = 0;
     int raw_sum = 0;
     int queue_threshold = 48; // k_trace_queue: hand out rays when fewer lanes than this still traverse
+    int queue_waves = 24;     // k_trace_queue: persistent waves per CU, at most
     // analysis builds: rays recorded by the last render (rt_test_dump_rays)
     float *d_ray_dump = nullptr;
     unsigned long long *d_ray_dump_count = nullptr;
@@ -291,14 +292,22 @@ void fill_stats(rt_ctx *c, rt_stats *st, uint64_t rays, float ms, double total_m
 }
 
 // kernel variant 1: zero the band counters, size the spill area, fill the launch record
-int prepare_persistent(rt_ctx *c, PersistLaunch &L, bool render) {
+enum LaunchKind { kLaunchRender, kLaunchPrimary, kLaunchRays };
+int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_rays = 0) {
+    const bool render = kind == kLaunchRender;
     // Render: waves_per_cu.  Textured scenes run the 128-VGPR instances (4 waves/SIMD): no point in launching more
-    // waves than are resident.  Primary rays / ray arrays are short and coherent, and every wave launched costs a ramp
-    // of atomics and first misses: 8 waves per CU measured best (1 M triangles, 1080p: 0.65 ms vs 0.86 at 16 and 1.06
-    // at 24; 4K: 1.77 vs 1.95 ms).
+    // waves than are resident.  Primary rays are short and coherent, and every wave launched costs a ramp of atomics
+    // and first misses: 8 waves per CU measured best (1 M triangles, 1080p: 0.65 ms vs 0.86 at 16 and 1.06 at 24; 4K:
+    // 1.77 vs 1.95 ms).  Ray arrays can be anything: the 288 M rays of a bench frame, replayed, take 82 / 49 / 39 ms
+    // at 8 / 16 / 24 waves per CU; so a ray array gets enough waves for ~16 rays per lane, between 4 per CU and
+    // RT_OPT_QUEUE_WAVES.
     int per_cu = c->waves_per_cu;
-    if (!render)
+    if (kind == kLaunchPrimary)
         per_cu = std::min(per_cu, 8);
+    else if (kind == kLaunchRays) {
+        const size_t want = (n_rays + (size_t)c->n_cus * 1024 - 1) / ((size_t)c->n_cus * 1024);
+        per_cu = std::min(per_cu, (int)std::min<size_t>((size_t)c->queue_waves, std::max<size_t>(want, 4)));
+    }
     else if (!c->wide.uv.empty())
         per_cu = std::min(per_cu, 16);
     L.grid_waves = c->n_cus * per_cu;
@@ -639,6 +648,10 @@ int rt_set_option(rt_ctx *c, int option, int64_t value) {
         if (value < 1 || value > 64) return fail(c, RT_E_ARG, "queue threshold 1..64");
         c->queue_threshold = (int)value;
         return RT_OK;
+    case RT_OPT_QUEUE_WAVES:
+        if (value < 1 || value > 32) return fail(c, RT_E_ARG, "queue waves per CU 1..32");
+        c->queue_waves = (int)value;
+        return RT_OK;
     case RT_OPT_SEED_SALT:
         if (value < 0) return fail(c, RT_E_ARG, "seed salt must not be negative");
         c->seed_salt = (unsigned long long)value;
@@ -683,6 +696,7 @@ int rt_get_option(rt_ctx *c, int option, int64_t *value) {
     case RT_OPT_SEED_SALT: *value = (int64_t)c->seed_salt; return RT_OK;
     case RT_OPT_RAW_SUM: *value = c->raw_sum; return RT_OK;
     case RT_OPT_QUEUE_THRESHOLD: *value = c->queue_threshold; return RT_OK;
+    case RT_OPT_QUEUE_WAVES: *value = c->queue_waves; return RT_OK;
     default: return fail(c, RT_E_ARG, "unknown option");
     }
 }
@@ -695,7 +709,7 @@ static int render_into(rt_ctx *c, float *d_fb, rt_stats *st, double t0) {
         HIPCHK(c, hipMemsetAsync(d_fb, 0, (size_t)c->nx * c->ny * 3 * sizeof(float), c->stream));
     PersistLaunch L;
     if (c->kernel_variant >= 1) {
-        int rc = prepare_persistent(c, L, true);
+        int rc = prepare_persistent(c, L, kLaunchRender);
         if (rc) return rc;
     }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -762,7 +776,7 @@ int rt_trace_primary(rt_ctx *c, int32_t *tri_id_host, float *t_host, rt_stats *s
     fill_frame(c, F);
     PersistLaunch L;
     if (c->kernel_variant >= 1) {
-        int rc2 = prepare_persistent(c, L, false);
+        int rc2 = prepare_persistent(c, L, kLaunchPrimary);
         if (rc2) {
             cleanup();
             return rc2;
@@ -816,7 +830,7 @@ int rt_trace_rays(rt_ctx *c, const float *org_dir6, int n_rays, int32_t *tri_id_
         if ((e = hipEventRecord(c->ev0, c->stream)) != hipSuccess) break;
         if (c->kernel_variant >= 1) {
             PersistLaunch L;
-            if (prepare_persistent(c, L, false) != RT_OK) {
+            if (prepare_persistent(c, L, kLaunchRays, (size_t)n_rays) != RT_OK) {
                 e = hipErrorOutOfMemory;
                 break;
             }
@@ -917,7 +931,7 @@ int rt_trace_rays_device(rt_ctx *c, const float *org_dir6_device, int n_rays, in
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
     PersistLaunch L;
-    rc = prepare_persistent(c, L, false);
+    rc = prepare_persistent(c, L, kLaunchRays, (size_t)n_rays);
     if (rc) return rc;
     L.threshold = c->queue_threshold;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));

@@ -40,6 +40,7 @@ OPT_MAX_DEPTH, OPT_HONOR_VFOV, OPT_LEAF_SIZE, OPT_BOX_MODE, OPT_SHARD_RANK, OPT_
 OPT_REFILL_THRESHOLD, OPT_WAVES_PER_CU, OPT_LDS_STACK, OPT_NODE_FORMAT, OPT_LEAF_BATCH, OPT_OCCUPANCY, OPT_TOPOLOGY = 8, 9, 10, 11, 12, 13, 14
 OPT_SHADE_BATCH, OPT_SWAP_BATCH, OPT_TAIL_SPLIT, OPT_SEED_SALT, OPT_RAW_SUM = 15, 16, 17, 18, 19
 OPT_QUEUE_THRESHOLD = 20
+OPT_QUEUE_WAVES = 21
 
 
 class RtStats(C.Structure):

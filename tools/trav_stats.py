@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--occ", type=int, default=None)
     ap.add_argument("--waves", type=int, default=None)
     ap.add_argument("--tail", type=int, default=None)
+    ap.add_argument("--queue-waves", type=lambda t: [int(x) for x in t.split(",")], default=[16])
     ap.add_argument("--replay", type=str, default=None, metavar="T1,T2,...",
                     help="record the frame's rays and trace them again with the ray-array kernel at these hand-out thresholds")
     args = ap.parse_args()
@@ -85,11 +86,12 @@ def main():
     eng.render()
     if args.replay:
         rays, render_ms = int(eng.last_stats.rays), eng.last_stats.kernel_ms
-        for thr in [int(x) for x in args.replay.split(",")]:
+        for thr, qw in [(int(x), w) for x in args.replay.split(",") for w in args.queue_waves]:
             eng.setOption(E.OPT_QUEUE_THRESHOLD, thr)
+            eng.setOption(E.OPT_QUEUE_WAVES, qw)
             for _ in range(2):
                 eng._check(eng._lib.rt_test_trace_dumped(eng._h, C.byref(eng.last_stats)), "rt_test_trace_dumped")
-            print(json.dumps({"kind": "replay", "threshold": thr, "rays": int(eng.last_stats.rays), "render_rays": rays,
+            print(json.dumps({"kind": "replay", "threshold": thr, "queue_waves": qw, "rays": int(eng.last_stats.rays), "render_rays": rays,
                               "render_ms_stats_build": render_ms, "replay_ms": eng.last_stats.kernel_ms,
                               "mrays_s": eng.last_stats.rays / eng.last_stats.kernel_ms / 1e3}), flush=True)
         eng._check(eng._lib.rt_test_dump_rays(eng._h, 0), "rt_test_dump_rays")
