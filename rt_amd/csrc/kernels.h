@@ -64,7 +64,7 @@ enum { kRingWords = 12 };
 enum { kStatIters = 0, kStatNodeLanes, kStatStalledLanes, kStatIdleLanes, kStatLeafFires, kStatLeafLanes, kStatLeafPrims,
        kStatRefills, kStatShadeLanes, kStatPrimaryLanes, kStatFetchLanes, kStatNodeIters, kStatRetiredLanes, kStatWaitLanes, kStatSpinPolls,
        kStatNodeLanesByBounce = 16 /* .. 23: bounce 0..6, 7+ */, kStatItersWithBounce = 24 /* .. 31 */,
-       kStatRefillClocks = 32, kStatTravClocks, kStatShadeClocks, kStatNodeClocks, kStatLeafClocks, kTravStats = 40 };
+       kStatRefillClocks = 32, kStatTravClocks, kStatShadeClocks, kStatNodeClocks, kStatLeafClocks, kStatPublishClocks, kStatFetchClocks, kStatPrimaryClocks, kTravStats = 40 };
 hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &F, const PersistLaunch &L, float *fb,
                              int32_t *ids, float *ts, hipStream_t stream);
 hipError_t launch_render(const KernelScene &S, const KernelFrame &F, int stack_entries, float *fb, hipStream_t stream);

@@ -784,8 +784,10 @@ __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const S
             const uint32_t nqy = ngy ? qa.w : qa.z, fqy = ngy ? qa.z : qa.w;
             const uint32_t nqz = ngz ? qb.y : qb.x, fqz = ngz ? qb.x : qb.y;
 #define RT_QB(W, SH) ((float)(((W) >> (SH)) & 0xFFu))
-            // (three v_pk_fma_f32 per child instead of six v_fma_f32 were tried: the register pairs they need cost more
-            // in spills at 80 VGPRs than the twelve instructions saved: 56.2 vs 53.2 ms on the bench frame)
+            // (three v_pk_fma_f32 per child instead of six v_fma_f32 were tried twice.  First the register pairs cost
+            // spills: 56.2 vs 53.2 ms.  With the child references in LDS the pairs fit -- 84 instead of 96 vector
+            // instructions in this block, no spill in the loop -- and the frame still took 47.0 vs 45.25 ms: a packed
+            // FMA does not issue at the rate of a plain one here.)
 #define RT_SLABQ(K_, SH, I)                                                                                            \
     {                                                                                                                  \
         float tn = fmaxf(fmaxf(__builtin_fmaf(RT_QB(nqx, SH), sx, ax), __builtin_fmaf(RT_QB(nqy, SH), sy, ay)),        \
@@ -1144,6 +1146,10 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
             st_sc1(P.round_flag + my_slot, P.frame_id * 64u + (slot_round >> 26) + 1u); // next round's tag
             has_pixel = false;
         }
+#ifdef RT_TRAV_STATS
+        const unsigned long long clk_pub = __builtin_readcyclecounter();
+        RT_STAT(kStatPublishClocks, clk_pub - clk_shade);
+#endif
         {
             uint32_t slot = 0;
             const bool need = !has_pixel && !retired && !waiting;
@@ -1193,6 +1199,10 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                 }
             }
         }
+#ifdef RT_TRAV_STATS
+        const unsigned long long clk_fetch = __builtin_readcyclecounter();
+        RT_STAT(kStatFetchClocks, clk_fetch - clk_pub);
+#endif
         RT_STAT(kStatPrimaryLanes, __popcll(ballot(has_pixel && !tracing && need_primary)));
         if (has_pixel && !tracing) {
             if (need_primary) {
@@ -1225,6 +1235,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
 #ifdef RT_TRAV_STATS
         const unsigned long long clk1 = __builtin_readcyclecounter();
         RT_STAT(kStatRefillClocks, clk1 - clk0);
+        RT_STAT(kStatPrimaryClocks, clk1 - clk_fetch);
 #endif
         // ---------------- traversal phase
         // Ballots are taken from comparisons of T.cur / T.pend made where they are needed: a ballot of a bool that

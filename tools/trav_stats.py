@@ -40,7 +40,9 @@ def stats(eng):
     clocks = float(int(out[32]) + int(out[33])) or 1.0  # wave clocks (s_memtime domain), summed over waves
     d["wave_time_share"] = {"refill_phase": int(out[32]) / clocks, "of_which_shading": int(out[34]) / clocks,
                             "traversal_phase": int(out[33]) / clocks,
-                            "of_which_node_steps": int(out[35]) / clocks, "of_which_leaf_tests": int(out[36]) / clocks}
+                            "of_which_node_steps": int(out[35]) / clocks, "of_which_leaf_tests": int(out[36]) / clocks,
+                            "refill_publish": int(out[37]) / clocks, "refill_fetch_and_restore": int(out[38]) / clocks,
+                            "refill_primary_and_begin": int(out[39]) / clocks}
     d["shade_lanes_per_refill"] = d["shade_lanes"] / max(d["refills"], 1)
     d["iters_per_refill"] = it / max(d["refills"], 1)
     return d
