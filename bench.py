@@ -87,6 +87,9 @@ def valu_issue(kernel_s):
                 # 4 cycles per wave64 instruction; quarter-rate ones (rcp, sqrt, f64 divide steps) take longer, so the
                 # estimate can pass 1: read it as "the VALU pipe never idles"
                 "busy_frac": v["SQ_INSTS_VALU"] / 1024.0 * 4.0 / cycles,
+                # cycles a SIMD spends per wave64 VALU instruction; tools/micro/valu_rate.hip reaches 3.0-3.4 on the
+                # node test's instruction mix with no dependencies (profiles/r01_valu_issue_rate.jsonl)
+                "cycles_per_inst_per_simd": cycles * 1024.0 / v["SQ_INSTS_VALU"],
                 "lane_utilisation": v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0)}
     except Exception:
         return None

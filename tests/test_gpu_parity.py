@@ -372,11 +372,11 @@ def test_cpp_console_session_equals_the_python_one(oracle, tmp_path):
     eng.close()
 
 
-@pytest.mark.parametrize("thr,n", [(48, 100000), (64, 777), (1, 5000), (48, 1)])
-def test_trace_rays_device_equals_host_path_and_oracle(oracle, thr, n):
+@pytest.mark.parametrize("thr,n,qw", [(48, 100000, 24), (64, 777, 24), (1, 5000, 1), (48, 1, 24), (48, 600000, 32)])
+def test_trace_rays_device_equals_host_path_and_oracle(oracle, thr, n, qw):
     """rt_trace_rays_device (rays and results in device memory, persistent waves with per-lane refill) against
-    rt_trace_rays and, on a sample, the oracle: ids and t bit-exact, for hand-out thresholds from 1 to 64 and ray
-    counts that do not fill a wave or a chunk."""
+    rt_trace_rays and, on a sample, the oracle: ids and t bit-exact, for hand-out thresholds from 1 to 64, ray
+    counts that do not fill a wave or a chunk, and wave counts from one per CU to more than a short array needs."""
     import ctypes as C
 
     # device buffers straight from the HIP runtime the library already loaded (torch would bring a second runtime
@@ -392,7 +392,7 @@ def test_trace_rays_device_equals_host_path_and_oracle(oracle, thr, n):
         return p
 
     tris = scenes.heightfield(40)
-    eng = _engine(tris, 32, 32, 1, 8, scenes.BENCH_CAMERA, {engine.OPT_QUEUE_THRESHOLD: thr})
+    eng = _engine(tris, 32, 32, 1, 8, scenes.BENCH_CAMERA, {engine.OPT_QUEUE_THRESHOLD: thr, engine.OPT_QUEUE_WAVES: qw})
     rng = np.random.default_rng(n)
     org = rng.uniform(-9, 9, size=(n, 3)).astype(np.float32)
     org[:, 1] = rng.uniform(0.5, 12, size=n).astype(np.float32)
