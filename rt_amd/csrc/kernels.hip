@@ -1040,6 +1040,8 @@ struct PersistArgs {
 // traversing nodes; the expensive primitive test runs only when `leaf_batch` lanes have one pending (or no
 // lane has node work), so it executes with many lanes instead of the one or two that happen to sit on a leaf.
 // OCC: waves per SIMD the register allocation is held to (__launch_bounds__' second argument).
+// (7 waves per SIMD, 72 VGPRs, 28 waves per CU on a 12-entry LDS stack: 34 spilled registers, none in the node step,
+// and 45.8 ms against 45.7 for 6 -- the seventh wave buys what its spills cost.)
 template <int MODE, int FMT, int SPEC, int OCC, bool TEX>
 __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFrame F, PersistArgs P, float *fb, int32_t *ids,
                                                    float *ts) {
