@@ -5,7 +5,8 @@ A "step" is one frame: one pass of the hot path (camera rays -> BVH traversal ->
 over every pixel this rank owns.  N=1 workload = BASELINE.json configs[2]: synthetic 1 002 528(+2)-triangle
 heightfield, diffuse path tracing, 1920x1080, 64 spp, max depth 8.  For N>1 the frame grows with N at fixed
 aspect and spp (weak scaling: per-GPU pixel count fixed), tiles are interleaved over ranks, and the frame is
-assembled on rank 0 with one RCCL reduce (each rank's frame is zero outside its tiles, so the sum is exact).
+assembled on rank 0 with one RCCL reduce (each rank's frame is zero outside its tiles, so the sum is exact), which
+runs while the next frame renders into a second buffer.
 
 rays = closest-hit queries (hit() calls, reference pbrt_engine.cu:371), counted on the device.
 Scene, BVH and camera are resident in HBM before the timed region; the frame stays on the device.
@@ -172,21 +173,44 @@ def main():
     if not sample_shard:
         eng.setShard(rank, world)
     kk = float(np.float32(1.0 / float(np.float32(args.spp))))
-    fb = torch.zeros((ny, nx, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
+    # Two frame buffers: frame k is assembled on rank 0 (RCCL's stream) while frame k + 1 renders (the library's
+    # stream), so the exchange costs the job one reduce at the end, not one per frame.
+    fbs = [torch.zeros((ny, nx, 3), dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(2 if world > 1 else 1)]
+    pending = [None, None]
+    frame_no = [0]
+
+    def finish(slot):
+        """Frame assembly of the buffer in `slot` has completed (host-side): the buffer may be rendered into again."""
+        if pending[slot] is not None:
+            pending[slot].wait()
+            torch.cuda.current_stream().synchronize()
+            pending[slot] = None
 
     def step():
-        st = eng.renderDevice(fb.data_ptr())
+        slot = frame_no[0] % len(fbs)
+        frame_no[0] += 1
+        fb = fbs[slot]
+        finish(slot)  # the reduce of two frames ago; the library memsets and renders on its own stream
+        st = eng.renderDevice(fb.data_ptr())  # returns when the frame is in fb
         if world > 1:
             # frame assembly on rank 0 (the host that writes the PPM): x + 0 is exact (tiles) / sums of clamped samples
             # (sample shards).  A reduce moves half the bytes of an all-reduce over the xGMI ring.
-            dist.reduce(fb, dst=0)
-            if sample_shard and rank == 0:
-                fb.mul_(kk).clamp_(max=1.0)
-            torch.cuda.synchronize()  # the next frame's memset runs on the library's own stream
+            if sample_shard:
+                dist.reduce(fb, dst=0)
+                if rank == 0:
+                    fb.mul_(kk).clamp_(max=1.0)
+                torch.cuda.synchronize()
+            else:
+                pending[slot] = dist.reduce(fb, dst=0, async_op=True)
         return st.rays, st.kernel_ms
+
+    def drain():
+        for slot in range(len(fbs)):
+            finish(slot)
 
     for _ in range(args.warmup):
         step()
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -196,10 +220,12 @@ def main():
         r, k = step()
         rays_local += r
         kernel_ms.append(k)
+    drain()  # every frame of the timed region is assembled on rank 0 before the clock stops
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    fb = fbs[(frame_no[0] - 1) % len(fbs)]  # the last frame
 
     if world > 1:
         small = "cpu" if rehearse else fb.device
