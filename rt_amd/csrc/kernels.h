@@ -44,6 +44,7 @@ struct PersistLaunch {
     int node_format; // 0 = WideNode (128 B float), 1 = QuantNode (64 B)
     int speculative; // 1 = postpone leaves (speculative traversal)
     int leaf_batch;
+    int primary_chunk = 256; // primary rays: slots per band-counter atomic (a multiple of 64)
     int occupancy; // 4, 6 or 8 waves per SIMD the kernel's registers are held to (quantized nodes only)
     int dual;        // render only: 1 = k_dual (two paths per lane); implies speculative traversal
     int shade_batch; // k_dual: lanes with shading work queued that end a traversal phase

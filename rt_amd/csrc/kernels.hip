@@ -956,9 +956,8 @@ __device__ __forceinline__ uint32_t band_begin(uint32_t n_tiles, uint32_t b) { r
 struct SlotQueue { // wave-uniform
     uint32_t next, end, bands_tried, round;
 };
-template <uint32_t CHUNK>
-__device__ __forceinline__ bool fetch_slot(unsigned int *band_counters, uint32_t n_tiles, uint32_t home, SlotQueue &q,
-                                           bool need, uint32_t &slot, uint32_t rounds, uint32_t &round) {
+__device__ __forceinline__ bool fetch_slot(const uint32_t CHUNK, unsigned int *band_counters, uint32_t n_tiles, uint32_t home,
+                                           SlotQueue &q, bool need, uint32_t &slot, uint32_t rounds, uint32_t &round) {
     const uint32_t lane = lane_id();
     for (int guard = 0; guard < 64; guard++) {
         const unsigned long long mask = ballot(need);
@@ -975,7 +974,7 @@ __device__ __forceinline__ bool fetch_slot(unsigned int *band_counters, uint32_t
             if (base >= band_slots * rounds) { // also true for an empty band (band_slots == 0)
                 q.bands_tried++;
             } else {
-                // band_slots is a multiple of 64 = CHUNK: a run never straddles two rounds
+                // band_slots is a multiple of 64, and CHUNK is 64 whenever rounds > 1: a run never straddles two rounds
                 const uint32_t r = rounds > 1u ? base / band_slots : 0u;
                 const uint32_t off = base - r * band_slots;
                 q.round = r;
@@ -1008,6 +1007,7 @@ struct PersistArgs {
     unsigned long long *ray_dump_count;
     unsigned long long ray_dump_cap;
     int rounds;            // 1 = off
+    uint32_t chunk;        // slots a wave takes per atomic on its band counter (64 when rounds > 1)
     uint32_t *round_state; // kRingWords words per slot
     uint32_t *round_flag;  // one word per slot: frame_id * 64 + the round whose start state the slot holds
     uint32_t frame_id;
@@ -1157,7 +1157,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
             const bool need = !has_pixel && !retired && !waiting;
             RT_STAT(kStatFetchLanes, __popcll(ballot(need)));
             uint32_t round = 0;
-            const bool got = fetch_slot<64u>(P.band_counters, n_tiles, home, q, need, slot, rounds, round);
+            const bool got = fetch_slot(P.chunk, P.band_counters, n_tiles, home, q, need, slot, rounds, round);
             if (need) {
                 if (!got) {
                     retired = true;
@@ -1544,7 +1544,7 @@ __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, 
             const bool need = w_status == RT_W_EMPTY && !retired;
             RT_STAT(kStatFetchLanes, __popcll(ballot(need)));
             uint32_t round = 0;
-            const bool got = fetch_slot<64u>(P.band_counters, n_tiles, home, q, need, slot, 1u, round);
+            const bool got = fetch_slot(64u, P.band_counters, n_tiles, home, q, need, slot, 1u, round);
             if (need) {
                 if (!got) {
                     retired = true;
@@ -1724,6 +1724,9 @@ hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &
     P.ray_dump_count = L.ray_dump_count;
     P.ray_dump_cap = L.ray_dump_cap;
     P.rounds = mode == 0 && L.rounds > 1 ? L.rounds : 1;
+    // primary rays are short: at 64 slots per atomic the eight band counters (one address each, 32 400 atomics for a
+    // 1080p frame) set the kernel's time -- 0.65 ms, 0.53 with 256 slots per atomic
+    P.chunk = mode == 1 && L.primary_chunk >= 64 ? (uint32_t)L.primary_chunk : 64u;
     P.round_state = L.round_state;
     P.round_flag = L.round_flag;
     P.frame_id = L.frame_id;

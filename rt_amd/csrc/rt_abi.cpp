@@ -39,6 +39,8 @@ struct rt_ctx {
     int raw_sum = 0;
     int queue_threshold = 48; // k_trace_queue: hand out rays when fewer lanes than this still traverse
     int queue_waves = 24;     // k_trace_queue: persistent waves per CU, at most
+    int primary_waves = 16;   // primary rays: persistent waves per CU, at most
+    int primary_chunk = 256;  // primary rays: pixel slots per band-counter atomic
     // analysis builds: rays recorded by the last render (rt_test_dump_rays)
     float *d_ray_dump = nullptr;
     unsigned long long *d_ray_dump_count = nullptr;
@@ -297,14 +299,15 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_ra
     const bool render = kind == kLaunchRender;
     // Render: waves_per_cu.  Textured scenes run the 128-VGPR instances (4 waves/SIMD): no point in launching more
     // waves than are resident.  Primary rays are short and coherent, and every wave launched costs a ramp of atomics
-    // and first misses: 8 waves per CU measured best (1 M triangles, 1080p: 0.65 ms vs 0.86 at 16 and 1.06 at 24; 4K:
-    // 1.77 vs 1.95 ms).  Ray arrays can be anything: the 288 M rays of a bench frame, replayed, take 82 / 49 / 39 ms
+    // and first misses: with 256 slots per atomic, 8 waves per CU measured best at 1080p (1 M triangles: 0.52 ms vs
+    // 0.57 at 12 and 0.62 at 16) and 16 at 2160p (1.03 ms vs 1.25 at 8).  Ray arrays can be anything: the 288 M rays of a bench frame, replayed, take 82 / 49 / 39 ms
     // at 8 / 16 / 24 waves per CU; so a ray array gets enough waves for ~16 rays per lane, between 4 per CU and
     // RT_OPT_QUEUE_WAVES.
     int per_cu = c->waves_per_cu;
-    if (kind == kLaunchPrimary)
-        per_cu = std::min(per_cu, 8);
-    else if (kind == kLaunchRays) {
+    if (kind == kLaunchPrimary) { // ~16 pixels per lane, between 8 waves per CU and RT_OPT_PRIMARY_WAVES
+        const size_t want = ((size_t)c->nx * c->ny / (size_t)std::max(c->shard_world, 1) + (size_t)c->n_cus * 1024 - 1) / ((size_t)c->n_cus * 1024);
+        per_cu = std::min(per_cu, (int)std::min<size_t>((size_t)c->primary_waves, std::max<size_t>(want, 8)));
+    } else if (kind == kLaunchRays) {
         const size_t want = (n_rays + (size_t)c->n_cus * 1024 - 1) / ((size_t)c->n_cus * 1024);
         per_cu = std::min(per_cu, (int)std::min<size_t>((size_t)c->queue_waves, std::max<size_t>(want, 4)));
     }
@@ -319,6 +322,7 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_ra
     L.shade_batch = c->shade_batch;
     L.swap_batch = c->swap_batch;
     L.leaf_batch = c->leaf_batch;
+    L.primary_chunk = c->primary_chunk;
     L.occupancy = c->occupancy;
     int spill_entries = c->wide.stack_entries - L.lds_entries;
     size_t words = (size_t)(spill_entries > 0 ? spill_entries : 1) * (size_t)L.grid_waves * 64;
@@ -648,6 +652,14 @@ int rt_set_option(rt_ctx *c, int option, int64_t value) {
         if (value < 1 || value > 64) return fail(c, RT_E_ARG, "queue threshold 1..64");
         c->queue_threshold = (int)value;
         return RT_OK;
+    case RT_OPT_PRIMARY_WAVES:
+        if (value < 1 || value > 32) return fail(c, RT_E_ARG, "primary waves per CU 1..32");
+        c->primary_waves = (int)value;
+        return RT_OK;
+    case RT_OPT_PRIMARY_CHUNK:
+        if (value < 64 || value > 65536 || value % 64) return fail(c, RT_E_ARG, "primary chunk: a multiple of 64, 64..65536");
+        c->primary_chunk = (int)value;
+        return RT_OK;
     case RT_OPT_QUEUE_WAVES:
         if (value < 1 || value > 32) return fail(c, RT_E_ARG, "queue waves per CU 1..32");
         c->queue_waves = (int)value;
@@ -697,6 +709,8 @@ int rt_get_option(rt_ctx *c, int option, int64_t *value) {
     case RT_OPT_RAW_SUM: *value = c->raw_sum; return RT_OK;
     case RT_OPT_QUEUE_THRESHOLD: *value = c->queue_threshold; return RT_OK;
     case RT_OPT_QUEUE_WAVES: *value = c->queue_waves; return RT_OK;
+    case RT_OPT_PRIMARY_WAVES: *value = c->primary_waves; return RT_OK;
+    case RT_OPT_PRIMARY_CHUNK: *value = c->primary_chunk; return RT_OK;
     default: return fail(c, RT_E_ARG, "unknown option");
     }
 }

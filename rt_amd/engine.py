@@ -41,6 +41,8 @@ OPT_REFILL_THRESHOLD, OPT_WAVES_PER_CU, OPT_LDS_STACK, OPT_NODE_FORMAT, OPT_LEAF
 OPT_SHADE_BATCH, OPT_SWAP_BATCH, OPT_TAIL_SPLIT, OPT_SEED_SALT, OPT_RAW_SUM = 15, 16, 17, 18, 19
 OPT_QUEUE_THRESHOLD = 20
 OPT_QUEUE_WAVES = 21
+OPT_PRIMARY_WAVES = 22
+OPT_PRIMARY_CHUNK = 23
 
 
 class RtStats(C.Structure):

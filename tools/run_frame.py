@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--shade", type=ints, default=[32])
     ap.add_argument("--swap", type=ints, default=[8])
     ap.add_argument("--tail", type=ints, default=[8])
+    ap.add_argument("--pwaves", type=ints, default=[8], help="primary rays: waves per CU")
+    ap.add_argument("--pchunk", type=ints, default=[256], help="primary rays: slots per atomic")
     args = ap.parse_args()
     tris = scenes.heightfield(args.grid)
     eng = rt_amd.PbrtEngine(args.nx, args.ny, args.spp, device=0)
@@ -73,15 +75,18 @@ def main():
             best = ms if best is None else min(best, ms)
         if args.frames:
             out.update(render_ms=best, rays=eng.last_stats.rays, mrays_s=eng.last_stats.rays / best / 1e3)
-        pbest = None
-        for _ in range(args.primary):
-            eng.tracePrimary()
-            ms = eng.last_stats.kernel_ms
-            pbest = ms if pbest is None else min(pbest, ms)
-        if args.primary:
-            out.update(primary_ms=pbest, primary_mrays_s=args.nx * args.ny / pbest / 1e3)
-        out.update(wide_nodes=eng.last_stats.wide_nodes, stack=eng.last_stats.stack_entries)
-        print(json.dumps(out), flush=True)
+        for pw, pc in itertools.product(args.pwaves, args.pchunk):
+            eng.setOption(E.OPT_PRIMARY_WAVES, pw)
+            eng.setOption(E.OPT_PRIMARY_CHUNK, pc)
+            pbest = None
+            for _ in range(args.primary):
+                eng.tracePrimary()
+                ms = eng.last_stats.kernel_ms
+                pbest = ms if pbest is None else min(pbest, ms)
+            if args.primary:
+                out.update(pwaves=pw, pchunk=pc, primary_ms=pbest, primary_mrays_s=args.nx * args.ny / pbest / 1e3)
+            out.update(wide_nodes=eng.last_stats.wide_nodes, stack=eng.last_stats.stack_entries)
+            print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
