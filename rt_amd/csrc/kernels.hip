@@ -1340,6 +1340,7 @@ struct QueueArgs {
     const float *rays; // origin[3], direction[3] per ray
     uint32_t n;
     unsigned int *next; // zeroed before the launch
+    uint32_t chunk;     // rays a wave takes per atomic on `next`
     int32_t *ids;
     float *ts;
     unsigned long long *ray_counter;
@@ -1365,14 +1366,14 @@ __global__ void __launch_bounds__(64, 6) k_trace_queue(KernelScene S, PersistArg
             if (idle == 0ull || exhausted) break;
             if (q_next == q_end) {
                 uint32_t base = 0;
-                if (lane == 0u) base = atomicAdd(Q.next, 256u);
+                if (lane == 0u) base = atomicAdd(Q.next, Q.chunk);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 if (base >= Q.n) {
                     exhausted = true;
                     break;
                 }
                 q_next = base;
-                q_end = base + 256u < Q.n ? base + 256u : Q.n;
+                q_end = base + Q.chunk < Q.n ? base + Q.chunk : Q.n;
             }
             const uint32_t avail = q_end - q_next;
             const uint32_t before = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
@@ -1687,6 +1688,7 @@ hipError_t launch_trace_queue(const KernelScene &S, const PersistLaunch &L, cons
     Q.rays = rays6;
     Q.n = n;
     Q.next = next;
+    Q.chunk = 256u; // 1024 and 4096 measured no better on 288 M rays (39.1 / 39.4 / 41.4 ms): one counter is enough here
     Q.ids = ids;
     Q.ts = ts;
     Q.ray_counter = ray_counter;
