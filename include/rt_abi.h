@@ -214,6 +214,11 @@ int rt_test_trav_stats(rt_ctx *ctx, uint64_t out[40]);
 int rt_test_dump_rays(rt_ctx *ctx, uint64_t capacity);
 int rt_test_trace_dumped(rt_ctx *ctx, rt_stats *stats);
 
+/* Analysis builds only: start and end time of every wave of the last render (constant 100 MHz device clock), as
+ * pairs out[2 w], out[2 w + 1] for the first n_waves waves; the first call switches the recording on.  Shows how
+ * long the end of a frame runs on thinning waves (tools/trav_stats.py --wave-times). */
+int rt_test_wave_times(rt_ctx *ctx, uint64_t *out, uint64_t n_waves);
+
 #ifdef __cplusplus
 }
 #endif

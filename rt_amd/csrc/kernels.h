@@ -58,12 +58,13 @@ struct PersistLaunch {
     float *ray_dump = nullptr;                     // analysis builds: rt_test_dump_rays
     unsigned long long *ray_dump_count = nullptr;
     unsigned long long ray_dump_cap = 0;
+    unsigned long long *wave_times = nullptr; // analysis builds: rt_test_wave_times
     unsigned long long *stats; // kTravStats counters, zeroed by the caller; only written by a -DRT_TRAV_STATS build
 };
 enum { kRingWords = 12 };
 // Lane-occupancy counters of the persistent kernel (analysis builds only, `make STATS=1`; tools/trav_stats.py)
 enum { kStatIters = 0, kStatNodeLanes, kStatStalledLanes, kStatIdleLanes, kStatLeafFires, kStatLeafLanes, kStatLeafPrims,
-       kStatRefills, kStatShadeLanes, kStatPrimaryLanes, kStatFetchLanes, kStatNodeIters, kStatRetiredLanes, kStatWaitLanes, kStatSpinPolls,
+       kStatRefills, kStatShadeLanes, kStatPrimaryLanes, kStatFetchLanes, kStatNodeIters, kStatRetiredLanes, kStatWaitLanes, kStatSpinPolls, kStatPollFails /* 15: polls of a round flag that found the record missing */,
        kStatNodeLanesByBounce = 16 /* .. 23: bounce 0..6, 7+ */, kStatItersWithBounce = 24 /* .. 31 */,
        kStatRefillClocks = 32, kStatTravClocks, kStatShadeClocks, kStatNodeClocks, kStatLeafClocks, kStatPublishClocks, kStatFetchClocks, kStatPrimaryClocks, kTravStats = 40 };
 hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &F, const PersistLaunch &L, float *fb,

@@ -45,6 +45,8 @@ struct rt_ctx {
     float *d_ray_dump = nullptr;
     unsigned long long *d_ray_dump_count = nullptr;
     unsigned long long ray_dump_cap = 0;
+    unsigned long long *d_wave_times = nullptr; // analysis builds: rt_test_wave_times
+    size_t wave_times_cap = 0;                  // waves
     // textures (lambertian albedo of triangles with texIdx != -1)
     void *d_uv = nullptr;
     DevTex *d_tex = nullptr;               // RT_TEX_NUM descriptors
@@ -363,6 +365,7 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_ra
         L.frame_id = c->frame_id;
     }
     L.stats = reinterpret_cast<unsigned long long *>(c->d_bands + 16);
+    if (render && c->d_wave_times && (size_t)L.grid_waves <= c->wave_times_cap) L.wave_times = c->d_wave_times;
     if (render && c->d_ray_dump) {
         L.ray_dump = c->d_ray_dump;
         L.ray_dump_count = c->d_ray_dump_count;
@@ -476,6 +479,7 @@ int rt_destroy(rt_ctx *c) {
     if (c->d_bands) (void)hipFree(c->d_bands);
     if (c->d_ray_dump) (void)hipFree(c->d_ray_dump);
     if (c->d_ray_dump_count) (void)hipFree(c->d_ray_dump_count);
+    if (c->d_wave_times) (void)hipFree(c->d_wave_times);
     if (c->d_tex) (void)hipFree(c->d_tex);
     for (int i = 0; i < RT_TEX_NUM; i++)
         if (c->d_texels[i]) (void)hipFree(c->d_texels[i]);
@@ -979,6 +983,27 @@ int rt_test_dump_rays(rt_ctx *c, uint64_t capacity) {
 #endif
 }
 
+int rt_test_wave_times(rt_ctx *c, uint64_t *out, uint64_t n_waves) {
+    if (!c) return RT_E_ARG;
+#ifdef RT_TRAV_STATS
+    if (!out || n_waves == 0 || n_waves > (1u << 20)) return fail(c, RT_E_ARG, "wave times: out and 1..2^20 waves");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->wave_times_cap < n_waves) {
+        if (c->d_wave_times) (void)hipFree(c->d_wave_times);
+        c->d_wave_times = nullptr;
+        c->wave_times_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_wave_times, n_waves * 2 * sizeof(unsigned long long)));
+        HIPCHK(c, hipMemset(c->d_wave_times, 0, n_waves * 2 * sizeof(unsigned long long)));
+        c->wave_times_cap = n_waves;
+    }
+    HIPCHK(c, hipMemcpy(out, c->d_wave_times, n_waves * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return RT_OK;
+#else
+    (void)out, (void)n_waves;
+    return fail(c, RT_E_UNSUPPORTED, "built without RT_TRAV_STATS (make STATS=1 builds librt_amd_stats.so)");
+#endif
+}
+
 int rt_test_trace_dumped(rt_ctx *c, rt_stats *st) {
     if (!c) return RT_E_ARG;
     if (!c->d_ray_dump) return fail(c, RT_E_ARG, "no recorded rays: rt_test_dump_rays, then render");
@@ -1011,7 +1036,7 @@ int rt_test_sincosf(float x, float *s, float *c) {
 
 int rt_test_tile_owner(int nx, int ny, int world, int32_t *owner) {
     if (nx <= 0 || ny <= 0 || world <= 0 || !owner) return RT_E_ARG;
-    // the rule of tile_pixel() / k_persistent in kernels.hip: 8x8 tiles, row-major tile index g, owner = g % world
+    // the rule of tile_xy() in kernels.hip: 8x8 tiles, row-major tile index g, owner = g % world
     const int tiles_x = (nx + 7) / 8;
     for (int j = 0; j < ny; j++)
         for (int i = 0; i < nx; i++) owner[(size_t)j * nx + i] = (int32_t)((((long)(j / 8)) * tiles_x + i / 8) % world);

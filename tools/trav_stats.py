@@ -16,7 +16,7 @@ from rt_amd import engine as E  # noqa: E402
 from rt_amd import scenes  # noqa: E402
 
 NAMES = ["iters", "node_lanes", "stalled_lanes", "idle_lanes", "leaf_fires", "leaf_lanes", "leaf_prims", "refills",
-         "shade_lanes", "primary_lanes", "fetch_lanes", "node_iters", "retired_lanes", "wait_lanes", "spin_polls"]
+         "shade_lanes", "primary_lanes", "fetch_lanes", "node_iters", "retired_lanes", "wait_lanes", "spin_polls", "poll_fails"]
 
 
 def stats(eng):
@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--occ", type=int, default=None)
     ap.add_argument("--waves", type=int, default=None)
     ap.add_argument("--tail", type=int, default=None)
+    ap.add_argument("--wave-times", action="store_true", help="when each wave of the render ends (share of waves still running over time)")
     ap.add_argument("--queue-waves", type=lambda t: [int(x) for x in t.split(",")], default=[16])
     ap.add_argument("--replay", type=str, default=None, metavar="T1,T2,...",
                     help="record the frame's rays and trace them again with the ray-array kernel at these hand-out thresholds")
@@ -85,6 +86,24 @@ def main():
     eng.setCamera(**scenes.BENCH_CAMERA)
     if args.replay:
         eng._check(eng._lib.rt_test_dump_rays(eng._h, 40 * args.nx * args.ny * args.spp // 10), "rt_test_dump_rays")
+    if args.wave_times:
+        nw = 256 * 32
+        wt = np.zeros(2 * nw, dtype=np.uint64)
+        eng._check(eng._lib.rt_test_wave_times(eng._h, wt.ctypes.data_as(C.c_void_p), nw), "rt_test_wave_times")
+        eng.render()
+        eng.render()
+        eng._check(eng._lib.rt_test_wave_times(eng._h, wt.ctypes.data_as(C.c_void_p), nw), "rt_test_wave_times")
+        w = wt.reshape(-1, 2)
+        w = w[w[:, 1] > 0].astype(np.float64)
+        t0, t1 = w[:, 0].min(), w[:, 1].max()
+        span = t1 - t0
+        ends = np.sort((w[:, 1] - t0) / span)
+        starts = np.sort((w[:, 0] - t0) / span)
+        print(json.dumps({"kind": "wave_times", "waves": int(w.shape[0]), "span_ms": span / 1e5, "kernel_ms": eng.last_stats.kernel_ms,
+                          "start_quantiles": [float(np.quantile(starts, q)) for q in (0.5, 0.9, 0.99, 1.0)],
+                          "end_quantiles": {str(q): float(np.quantile(ends, q)) for q in (0.0, 0.01, 0.1, 0.25, 0.5, 0.75, 0.9, 0.99)},
+                          "mean_running_share": float(((w[:, 1] - w[:, 0]) / span).mean())}), flush=True)
+        return
     eng.render()
     if args.replay:
         rays, render_ms = int(eng.last_stats.rays), eng.last_stats.kernel_ms
