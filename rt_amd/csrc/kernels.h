@@ -52,6 +52,7 @@ struct PersistLaunch {
     // rounds (render only): the frame is walked `rounds` times, pixels hand their state on between rounds; see
     // "Rounds" at k_persistent
     int rounds;            // 1 = off; at most 63 and at most ns
+    int round_end[64];     // round r runs the samples [round_end[r - 1], round_end[r]) of a pixel; round_end[rounds - 1] = ns
     uint32_t *round_state; // kRingWords words per slot (n_local_tiles * 64 slots)
     uint32_t *round_flag;  // one word per slot; zeroed once at allocation
     uint32_t frame_id;     // never 0, below 2^26; flags of earlier launches compare unequal: no clearing per frame

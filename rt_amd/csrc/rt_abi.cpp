@@ -31,7 +31,7 @@ struct rt_ctx {
     // NX/NY/NS, include/RT/pbrt_engine.h:24-26 ; ITER_NUM, pbrt_engine.cu:458
     int nx = 640, ny = 360, ns = 10, max_depth = 50;
     int honor_vfov = 0, leaf_size = 2, box_mode = 0, shard_rank = 0, shard_world = 1, kernel_variant = 2;
-    int shade_batch = 32, swap_batch = 8, tail_split = 8;
+    int shade_batch = 32, swap_batch = 8, tail_split = 8, tail_taper = 150;
     uint32_t *d_ring_state = nullptr, *d_ring_flag = nullptr;
     size_t ring_items = 0;
     uint32_t frame_id = 0;
@@ -360,6 +360,19 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_ra
             c->frame_id = 1;
         }
         L.rounds = rounds;
+        // Shares of the rounds: boundary r at ns * (1 - (1 - r/R)^p), p = RT_OPT_TAIL_TAPER / 100.  p = 1: equal
+        // shares; p > 1: the last rounds are short, and what is still running when the work has been handed out is
+        // a short piece per lane.  Kept strictly increasing (a round runs at least one sample).
+        {
+            const double p = c->tail_taper / 100.0;
+            int prev = 0;
+            for (int r = 0; r < rounds; r++) {
+                int k = r + 1 == rounds ? c->ns : (int)std::floor(c->ns * (1.0 - std::pow(1.0 - double(r + 1) / rounds, p)));
+                k = std::max(k, prev + 1);
+                k = std::min(k, c->ns - (rounds - 1 - r)); // leave one sample for every later round
+                L.round_end[r] = prev = k;
+            }
+        }
         L.round_state = c->d_ring_state;
         L.round_flag = c->d_ring_flag;
         L.frame_id = c->frame_id;
@@ -679,6 +692,10 @@ int rt_set_option(rt_ctx *c, int option, int64_t value) {
         if (value < 1 || value > 63) return fail(c, RT_E_ARG, "rounds 1..63");
         c->tail_split = (int)value;
         return RT_OK;
+    case RT_OPT_TAIL_TAPER:
+        if (value < 100 || value > 400) return fail(c, RT_E_ARG, "taper 100..400 (percent)");
+        c->tail_taper = (int)value;
+        return RT_OK;
     case RT_OPT_TOPOLOGY:
         if (value != 0 && value != 1) return fail(c, RT_E_ARG, "topology 0 or 1");
         if (c->topology != (int)value) c->scene_on_device = false;
@@ -709,6 +726,7 @@ int rt_get_option(rt_ctx *c, int option, int64_t *value) {
     case RT_OPT_SHADE_BATCH: *value = c->shade_batch; return RT_OK;
     case RT_OPT_SWAP_BATCH: *value = c->swap_batch; return RT_OK;
     case RT_OPT_TAIL_SPLIT: *value = c->tail_split; return RT_OK;
+    case RT_OPT_TAIL_TAPER: *value = c->tail_taper; return RT_OK;
     case RT_OPT_SEED_SALT: *value = (int64_t)c->seed_salt; return RT_OK;
     case RT_OPT_RAW_SUM: *value = c->raw_sum; return RT_OK;
     case RT_OPT_QUEUE_THRESHOLD: *value = c->queue_threshold; return RT_OK;

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--shade", type=ints, default=[32])
     ap.add_argument("--swap", type=ints, default=[8])
     ap.add_argument("--tail", type=ints, default=[8])
+    ap.add_argument("--taper", type=ints, default=[100])
     ap.add_argument("--pwaves", type=ints, default=[8], help="primary rays: waves per CU")
     ap.add_argument("--pchunk", type=ints, default=[256], help="primary rays: slots per atomic")
     args = ap.parse_args()
@@ -48,7 +49,7 @@ def main():
     eng.setMaxDepth(args.depth)
     eng.setCamera(**scenes.BENCH_CAMERA)
     nodes = None
-    for leaf, bm, kv, th, wv, ld, fm, lb, oc, tp, sb, wb, ts in itertools.product(args.leaf, args.box_mode, args.kernel, args.threshold, args.waves, args.lds, args.fmt, args.batch, args.occ, args.topo, args.shade, args.swap, args.tail):
+    for leaf, bm, kv, th, wv, ld, fm, lb, oc, tp, sb, wb, ts, tap in itertools.product(args.leaf, args.box_mode, args.kernel, args.threshold, args.waves, args.lds, args.fmt, args.batch, args.occ, args.topo, args.shade, args.swap, args.tail, args.taper):
         eng.setOption(E.OPT_LEAF_SIZE, leaf)
         eng.setOption(E.OPT_BOX_MODE, bm)
         eng.setOption(E.OPT_KERNEL, kv)
@@ -62,12 +63,13 @@ def main():
         eng.setOption(E.OPT_SHADE_BATCH, sb)
         eng.setOption(E.OPT_SWAP_BATCH, wb)
         eng.setOption(E.OPT_TAIL_SPLIT, ts)
+        eng.setOption(E.OPT_TAIL_TAPER, tap)
         if nodes is None:
             eng.buildBvh()
             nodes = eng.getBvhNodes()
         else:
             eng.setBvhNodes(nodes)
-        out = {"leaf": leaf, "box_mode": bm, "kernel": kv, "thr": th, "waves": wv, "lds": ld, "fmt": fm, "batch": lb, "occ": oc, "topo": tp, "shade": sb, "swap": wb, "tail": ts}
+        out = {"leaf": leaf, "box_mode": bm, "kernel": kv, "thr": th, "waves": wv, "lds": ld, "fmt": fm, "batch": lb, "occ": oc, "topo": tp, "shade": sb, "swap": wb, "tail": ts, "taper": tap}
         best = None
         for _ in range(args.frames):
             eng.render()
