@@ -666,6 +666,7 @@ struct StackRef {
     uint32_t *spill;    // this lane's column, stride spill_stride
     uint32_t sp0;       // Trav::sp of an empty stack (LDS address of s_stack + lane * 4)
     uint32_t lds_limit; // sp0 of lane 0 + lds_entries * 256: a Trav::sp below it names an entry in LDS
+    uint32_t fast_limit; // lds_limit - 512: a stack below it stays in LDS through one node step and the leaf parking
     uint32_t child16;   // LDS address of s_child[lane]
     int lds_entries;
     uint32_t spill_stride;
@@ -675,6 +676,7 @@ __device__ __forceinline__ void stack_ref_init(StackRef &K, uint32_t lane, uint3
     K.spill = spill + (size_t)blockIdx.x * 64u + lane;
     K.sp0 = lds_addr(s_stack) + lane * 4u;
     K.lds_limit = lds_addr(s_stack) + (uint32_t)lds_entries * 256u;
+    K.fast_limit = lds_entries >= 2 ? K.lds_limit - 512u : 0u;
     K.child16 = lds_addr(s_child) + lane * 16u;
     K.lds_entries = lds_entries;
     K.spill_stride = total_lanes;
@@ -750,7 +752,7 @@ __device__ __forceinline__ uint32_t pop_or_none(const StackRef &K, uint32_t &sp)
 template <int FMT>
 __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const StackRef &K) {
     // every stack entry this step can touch is in LDS (entries [e - 1, e + 2] for a stack of e): the common case
-    const bool fast = T.sp + 512u < K.lds_limit;
+    const bool fast = T.sp < K.fast_limit;
     {
         uint32_t k0, k1, k2, k3;
         if (FMT == 0) {
@@ -1306,6 +1308,9 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
 #ifdef RT_TRAV_STATS
                 const unsigned long long clk_n0 = __builtin_readcyclecounter();
 #endif
+                // a stack that starts the step below fast_limit ends it at most three entries higher: the pop of the
+                // leaf parking below finds its entry in LDS too
+                const bool lds_only = T.sp < K.fast_limit;
                 if (!(T.cur & kLeafBit)) node_step<FMT>(T, S, K);
 #ifdef RT_TRAV_STATS
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the step's stack reads have come back
@@ -1314,7 +1319,16 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                 // park a reached leaf in the pending slot and go on with the next stack entry
                 if (T.pend == RT_REF_NONE && T.cur != RT_REF_NONE && (T.cur & kLeafBit)) {
                     T.pend = T.cur;
-                    T.cur = pop_or_none(K, T.sp);
+                    if (__builtin_expect(lds_only, 1)) {
+                        if (T.sp == K.sp0) {
+                            T.cur = RT_REF_NONE;
+                        } else {
+                            T.sp -= 256u;
+                            T.cur = *stk_lds(T.sp);
+                        }
+                    } else {
+                        T.cur = pop_or_none(K, T.sp);
+                    }
                 }
                 const bool want_leaf = T.pend != RT_REF_NONE;
                 const unsigned long long leaf_mask = ballot(want_leaf);
