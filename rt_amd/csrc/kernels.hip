@@ -863,20 +863,20 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) {
 // one-lane loop had, so the result is the same.  The primitive test is ~75 vector instructions; the exchange is
 // LDS traffic and ~25.  Owners without a helper, and primitives beyond the second, take the loop.
 // Must be called by all 64 lanes.  xchg = LDS address of s_child (the leaf exchange's fields).
-__device__ __forceinline__ void leaf_fire(Trav &T, const KernelScene &S, const Ray &cur, bool want_leaf, uint32_t xchg) {
+// leaf_mask = ballot(want_leaf), which the caller has.
+__device__ __forceinline__ void leaf_fire(Trav &T, const KernelScene &S, const Ray &cur, bool want_leaf,
+                                          unsigned long long leaf_mask, uint32_t xchg) {
     const uint32_t ref = T.pend;
     const uint32_t start = ref & kLeafStartMask;
-    const uint32_t cnt = want_leaf ? ((ref >> 28) & 7u) + 1u : 0u;
-    const bool two = cnt >= 2u;
-    const unsigned long long own_m = ballot(two), free_m = ballot(!want_leaf);
+    // masks stay scalar: owners = lanes whose leaf holds a second primitive, free = lanes without a leaf
+    const bool has2 = (ref & 0x70000000u) != 0u, two = has2 && want_leaf;
+    const unsigned long long own_m = ballot(has2) & leaf_mask, free_m = ~leaf_mask;
     const uint32_t n_own = (uint32_t)__popcll(own_m), n_free = (uint32_t)__popcll(free_m);
     const uint32_t pairs = n_own < n_free ? n_own : n_free; // wave-uniform
-    const uint32_t rank = mbcnt64(two ? own_m : free_m);
+    const uint32_t rank = want_leaf ? mbcnt64(own_m) : mbcnt64(free_m);
     const bool exporting = two && rank < pairs, helping = !want_leaf && rank < pairs;
     const uint32_t slot = xchg + rank * 4u;
-    Ray lr = cur;
-    uint32_t lp = start;
-    if (pairs != 0u) {
+    {
         if (exporting) {
             *(lu32 *)(uintptr_t)(slot + 0u * 256u) = __float_as_uint(cur.o.x);
             *(lu32 *)(uintptr_t)(slot + 1u * 256u) = __float_as_uint(cur.o.y);
@@ -886,8 +886,12 @@ __device__ __forceinline__ void leaf_fire(Trav &T, const KernelScene &S, const R
             *(lu32 *)(uintptr_t)(slot + 5u * 256u) = __float_as_uint(cur.d.z);
             *(lu32 *)(uintptr_t)(slot + 6u * 256u) = start + 1u;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    Ray lr = cur;
+    uint32_t lp = start;
+    {
         if (helping) {
             lr.o.x = __uint_as_float(*(lu32 *)(uintptr_t)(slot + 0u * 256u));
             lr.o.y = __uint_as_float(*(lu32 *)(uintptr_t)(slot + 1u * 256u));
@@ -917,6 +921,7 @@ __device__ __forceinline__ void leaf_fire(Trav &T, const KernelScene &S, const R
             T.best_t = t;
             T.best_rank = (int)start;
         }
+        const uint32_t cnt = ((ref >> 28) & 7u) + 1u;
         uint32_t i = 1u;
         if (exporting) {
             const float t1 = __uint_as_float(*(lu32 *)(uintptr_t)(slot + 0u * 256u));
@@ -1347,7 +1352,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
 #ifdef RT_TRAV_STATS
                         const unsigned long long clk_l0 = __builtin_readcyclecounter();
 #endif
-                        leaf_fire(T, S, cur, want_leaf, lds_addr(s_child));
+                        leaf_fire(T, S, cur, want_leaf, leaf_mask, lds_addr(s_child));
 #ifdef RT_TRAV_STATS
                         RT_STAT(kStatLeafClocks, __builtin_readcyclecounter() - clk_l0);
 #endif
@@ -1453,7 +1458,7 @@ __global__ void __launch_bounds__(64, 6) k_trace_queue(KernelScene S, PersistArg
             if (leaf_mask != 0ull) {
                 const unsigned long long node_mask = ballot(tracing && !(T.cur & kLeafBit));
                 if (node_mask == 0ull || (int)__popcll(leaf_mask) >= P.leaf_batch)
-                    leaf_fire(T, S, cur, want_leaf, lds_addr(s_child));
+                    leaf_fire(T, S, cur, want_leaf, leaf_mask, lds_addr(s_child));
             }
             if (tracing && T.cur == RT_REF_NONE && T.pend == RT_REF_NONE) {
                 tracing = false;
