@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--swap", type=ints, default=[8])
     ap.add_argument("--tail", type=ints, default=[8])
     ap.add_argument("--taper", type=ints, default=[100])
-    ap.add_argument("--pwaves", type=ints, default=[8], help="primary rays: waves per CU")
+    ap.add_argument("--pwaves", type=ints, default=[16], help="primary rays: waves per CU")
     ap.add_argument("--pchunk", type=ints, default=[256], help="primary rays: slots per atomic")
     args = ap.parse_args()
     tris = scenes.heightfield(args.grid)
