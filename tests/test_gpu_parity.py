@@ -122,6 +122,21 @@ def test_primary_ids_100k_1080p(oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("waves,chunk,nx,ny", [(1, 64, 93, 61), (16, 256, 93, 61), (8, 1024, 200, 120), (32, 65536, 64, 64), (4, 192, 8, 8)])
+def test_primary_launch_shapes(oracle, waves, chunk, nx, ny):
+    """Primary rays take their pixels `chunk` slots per atomic from eight band counters, with few or many waves per CU:
+    hit ids and t are the oracle's whatever the launch looks like (chunks larger than a band, frames smaller than a
+    chunk, more waves than tiles)."""
+    tris, cam = scenes.heightfield(40), scenes.BENCH_CAMERA
+    eng = _engine(tris, nx, ny, 1, 8, cam, {engine.OPT_PRIMARY_WAVES: waves, engine.OPT_PRIMARY_CHUNK: chunk})
+    ids, ts = eng.tracePrimary()
+    assert eng.last_stats.rays == nx * ny
+    ocam = oracle.camera(cam["lookfrom"], cam["lookat"], 40.0, nx / ny, cam["aperture"], cam["dist_to_focus"])
+    ids_o, ts_o, _ = oracle.trace_primary(tris, eng.getBvhNodes(), ocam, nx, ny, mode=1, threads=8)
+    assert ids.tobytes() == ids_o.tobytes() and ts.tobytes() == ts_o.tobytes()
+    eng.close()
+
+
 def test_trace_rays_incoherent(oracle):
     """Incoherent rays (bounce-like): random origins above the surface, random directions."""
     tris = scenes.heightfield(96)
@@ -213,16 +228,18 @@ def test_two_paths_per_lane_kernel_bit_exact(oracle, fmt, occ, thr, batch, shade
         eng.close()
 
 
-@pytest.mark.parametrize("kernel,tail,ns,waves,world", [(2, 1, 16, 24, 1), (2, 2, 16, 2, 1), (2, 8, 17, 1, 1), (2, 63, 64, 3, 1), (1, 3, 5, 24, 1),
-                                                        (2, 8, 4, 2, 1), (2, 8, 3, 2, 1), (2, 8, 1, 2, 1), (2, 5, 21, 2, 3)])
-def test_tail_split_does_not_change_the_image(oracle, kernel, tail, ns, waves, world):
+@pytest.mark.parametrize("kernel,tail,ns,waves,world,taper", [(2, 1, 16, 24, 1, 150), (2, 2, 16, 2, 1, 150), (2, 8, 17, 1, 1, 150), (2, 63, 64, 3, 1, 100),
+                                                              (1, 3, 5, 24, 1, 150), (2, 8, 4, 2, 1, 150), (2, 8, 3, 2, 1, 400), (2, 8, 1, 2, 1, 150),
+                                                              (2, 5, 21, 2, 3, 150), (2, 8, 10, 4, 1, 400), (2, 16, 64, 24, 1, 250), (2, 63, 64, 3, 1, 400)])
+def test_tail_split_does_not_change_the_image(oracle, kernel, tail, ns, waves, world, taper):
     """RT_OPT_TAIL_SPLIT: the frame is walked in rounds and pixels hand their state (RNG, sum, sample count) to
     whichever lane takes their slot next round.  Whatever the number of rounds (more rounds than samples included),
     few waves (a lane waits for records its own wave has to write) or many (most lanes never see a pixel), sharded
     or not: the oracle's image, bit for bit, twice in a row (a record's flag names frame and round; nothing is
-    cleared between frames)."""
+    cleared between frames).  The rounds' shares taper (RT_OPT_TAIL_TAPER): equal shares, the default and the steepest
+    taper, also where the taper would leave later rounds without a sample (as many rounds as samples)."""
     tris, cam, nx, ny, depth = scenes.heightfield(40), scenes.BENCH_CAMERA, 93, 61, 6
-    opts = {engine.OPT_KERNEL: kernel, engine.OPT_TAIL_SPLIT: tail, engine.OPT_WAVES_PER_CU: waves}
+    opts = {engine.OPT_KERNEL: kernel, engine.OPT_TAIL_SPLIT: tail, engine.OPT_WAVES_PER_CU: waves, engine.OPT_TAIL_TAPER: taper}
     eng = _engine(tris, nx, ny, ns, depth, cam, opts)
     nodes = eng.getBvhNodes()
     ocam = oracle.camera(cam["lookfrom"], cam["lookat"], 40.0, nx / ny, cam["aperture"], cam["dist_to_focus"])
