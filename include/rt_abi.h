@@ -215,8 +215,9 @@ int rt_test_trav_stats(rt_ctx *ctx, uint64_t out[40]);
 int rt_test_dump_rays(rt_ctx *ctx, uint64_t capacity);
 int rt_test_trace_dumped(rt_ctx *ctx, rt_stats *stats);
 
-/* Analysis builds only: start and end time of every wave of the last render (constant 100 MHz device clock), as
- * pairs out[2 w], out[2 w + 1] for the first n_waves waves; the first call switches the recording on.  Shows how
+/* Analysis builds only: for every wave of the last render, on the constant 100 MHz device clock: out[3 w] = start,
+ * out[3 w + 1] = end, out[3 w + 2] = when it first found every band handed out; for the first n_waves waves; the first
+ * call switches the recording on.  Shows how
  * long the end of a frame runs on thinning waves (tools/trav_stats.py --wave-times). */
 int rt_test_wave_times(rt_ctx *ctx, uint64_t *out, uint64_t n_waves);
 

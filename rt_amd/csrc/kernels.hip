@@ -973,11 +973,18 @@ __device__ __forceinline__ uint32_t band_begin(uint32_t n_tiles, uint32_t b) { r
 // With rounds > 1 (render only) every band is walked `rounds` times, round-major: a band's counter runs over
 // rounds * band_slots, and the slot's round comes back in `round` (see "Rounds" at k_persistent).
 struct SlotQueue { // wave-uniform
-    uint32_t next, end, empty, cursor, round; // empty: bit b = band b was found exhausted; cursor: the band last taken from
+    uint32_t next, end;   // the wave's run, in the coordinates of its band's counter (round * band_slots + offset)
+    uint32_t round;       // round of q.next
+    uint32_t band_slots;  // slots per round of the band the run comes from
+    uint32_t base_slot;   // first slot of that band
+    uint32_t empty, cursor; // empty: bit b = band b was found exhausted; cursor: the band last taken from
 };
 __device__ __forceinline__ bool fetch_slot(const uint32_t CHUNK, unsigned int *band_counters, uint32_t n_tiles, uint32_t home,
                                            SlotQueue &q, bool need, uint32_t &slot, uint32_t rounds, uint32_t &round) {
     const uint32_t lane = lane_id();
+    // (After the last slot has been handed out a wave still holds what is left of its own run, which only its own
+    // lanes can take.  Runs of 16 instead of 64 slots in the last round were measured: 41.8 vs 41.7 ms, no gain -- what
+    // is left then is one piece per lane, 5 % of all iterations at 12 lanes per wave.)
     for (int guard = 0; guard < 64; guard++) {
         const unsigned long long mask = ballot(need);
         if (mask == 0ull) break;
@@ -999,23 +1006,31 @@ __device__ __forceinline__ bool fetch_slot(const uint32_t CHUNK, unsigned int *b
             if (base >= band_slots * rounds) { // also true for an empty band (band_slots == 0)
                 q.empty |= 1u << b;
             } else {
-                // band_slots is a multiple of 64, and CHUNK is 64 whenever rounds > 1: a run never straddles two rounds
-                const uint32_t r = rounds > 1u ? base / band_slots : 0u;
-                const uint32_t off = base - r * band_slots;
-                q.round = r;
-                q.next = begin * 64u + off;
-                q.end = begin * 64u + (off + CHUNK < band_slots ? off + CHUNK : band_slots);
+                // the run stays in counter coordinates: it may cross from one round into the next (runs of different
+                // lengths share a counter), and every slot it covers must be taken
+                q.round = rounds > 1u ? base / band_slots : 0u;
+                q.band_slots = band_slots;
+                q.base_slot = begin * 64u;
+                q.next = base;
+                q.end = base + CHUNK < band_slots * rounds ? base + CHUNK : band_slots * rounds;
             }
             continue;
         }
         const uint32_t cnt = (uint32_t)__popcll(mask);
         const uint32_t before = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         if (need && before < avail) {
-            slot = q.next + before;
-            round = q.round;
+            uint32_t r = q.round;
+            uint32_t off = q.next + before - r * q.band_slots; // a run is shorter than a round: at most one boundary
+            if (off >= q.band_slots) {
+                off -= q.band_slots;
+                r++;
+            }
+            slot = q.base_slot + off;
+            round = r;
             need = false;
         }
         q.next += cnt < avail ? cnt : avail;
+        if (q.next - q.round * q.band_slots >= q.band_slots) q.round++;
     }
     return !need;
 }
@@ -1031,7 +1046,7 @@ struct PersistArgs {
     float *ray_dump;                     // analysis builds: where k_persistent records the rays it traces (or nullptr)
     unsigned long long *ray_dump_count;
     unsigned long long ray_dump_cap;
-    unsigned long long *wave_times;      // analysis builds: [2 * wave] = start, end (s_memrealtime), or nullptr
+    unsigned long long *wave_times;      // analysis builds: [3 * wave] = start, end, all bands dry (s_memrealtime), or nullptr
     int rounds;            // 1 = off
     int round_end[64];     // sample count at which round r hands the pixel on (the last one: ns)
     uint32_t chunk;        // slots a wave takes per atomic on its band counter (64 when rounds > 1)
@@ -1078,7 +1093,8 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
     const uint32_t home = xcc_id();
     const uint32_t n_tiles = (uint32_t)F.n_local_tiles;
     SlotQueue q;
-    q.next = q.end = q.empty = q.round = 0u;
+    q.next = q.end = q.empty = q.round = q.base_slot = 0u;
+    q.band_slots = 1u;
     q.cursor = (home + (blockIdx.x >> 3)) & 7u;
 
     // per-lane path state
@@ -1104,6 +1120,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
 #ifdef RT_TRAV_STATS
     unsigned long long st[kTravStats] = {0};
     const unsigned long long wave_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long wave_t_dry = 0; // when this wave first found every band handed out
 #endif
 
     for (;;) {
@@ -1187,6 +1204,9 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
             RT_STAT(kStatFetchLanes, __popcll(ballot(need)));
             uint32_t round = 0;
             const bool got = fetch_slot(P.chunk, P.band_counters, n_tiles, home, q, need, slot, rounds, round);
+#ifdef RT_TRAV_STATS
+            if (q.empty == 0xFFu && wave_t_dry == 0) wave_t_dry = __builtin_amdgcn_s_memrealtime();
+#endif
             if (need) {
                 if (!got) {
                     retired = true;
@@ -1376,8 +1396,9 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
         for (int i = 0; i < kTravStats; i++)
             if (st[i]) atomicAdd(&P.stats[i], st[i]);
     if (lane == 0 && P.wave_times) {
-        P.wave_times[2 * (size_t)blockIdx.x] = wave_t0;
-        P.wave_times[2 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        P.wave_times[3 * (size_t)blockIdx.x] = wave_t0;
+        P.wave_times[3 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        P.wave_times[3 * (size_t)blockIdx.x + 2] = wave_t_dry;
     }
 #endif
 }
@@ -1534,7 +1555,8 @@ __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, 
     const uint32_t home = xcc_id();
     const uint32_t n_tiles = (uint32_t)F.n_local_tiles;
     SlotQueue q;
-    q.next = q.end = q.empty = q.round = 0u;
+    q.next = q.end = q.empty = q.round = q.base_slot = 0u;
+    q.band_slots = 1u;
     q.cursor = (home + (blockIdx.x >> 3)) & 7u;
 
     PathRegs pt, pw;

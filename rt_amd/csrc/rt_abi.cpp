@@ -1010,11 +1010,11 @@ int rt_test_wave_times(rt_ctx *c, uint64_t *out, uint64_t n_waves) {
         if (c->d_wave_times) (void)hipFree(c->d_wave_times);
         c->d_wave_times = nullptr;
         c->wave_times_cap = 0;
-        HIPCHK(c, hipMalloc((void **)&c->d_wave_times, n_waves * 2 * sizeof(unsigned long long)));
-        HIPCHK(c, hipMemset(c->d_wave_times, 0, n_waves * 2 * sizeof(unsigned long long)));
+        HIPCHK(c, hipMalloc((void **)&c->d_wave_times, n_waves * 3 * sizeof(unsigned long long)));
+        HIPCHK(c, hipMemset(c->d_wave_times, 0, n_waves * 3 * sizeof(unsigned long long)));
         c->wave_times_cap = n_waves;
     }
-    HIPCHK(c, hipMemcpy(out, c->d_wave_times, n_waves * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out, c->d_wave_times, n_waves * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return RT_OK;
 #else
     (void)out, (void)n_waves;

@@ -88,12 +88,12 @@ def main():
         eng._check(eng._lib.rt_test_dump_rays(eng._h, 40 * args.nx * args.ny * args.spp // 10), "rt_test_dump_rays")
     if args.wave_times:
         nw = 256 * 32
-        wt = np.zeros(2 * nw, dtype=np.uint64)
+        wt = np.zeros(3 * nw, dtype=np.uint64)
         eng._check(eng._lib.rt_test_wave_times(eng._h, wt.ctypes.data_as(C.c_void_p), nw), "rt_test_wave_times")
         eng.render()
         eng.render()
         eng._check(eng._lib.rt_test_wave_times(eng._h, wt.ctypes.data_as(C.c_void_p), nw), "rt_test_wave_times")
-        w = wt.reshape(-1, 2)
+        w = wt.reshape(-1, 3)
         w = w[w[:, 1] > 0].astype(np.float64)
         t0, t1 = w[:, 0].min(), w[:, 1].max()
         span = t1 - t0
@@ -102,6 +102,7 @@ def main():
         print(json.dumps({"kind": "wave_times", "waves": int(w.shape[0]), "span_ms": span / 1e5, "kernel_ms": eng.last_stats.kernel_ms,
                           "start_quantiles": [float(np.quantile(starts, q)) for q in (0.5, 0.9, 0.99, 1.0)],
                           "end_quantiles": {str(q): float(np.quantile(ends, q)) for q in (0.0, 0.01, 0.1, 0.25, 0.5, 0.75, 0.9, 0.99)},
+                          "dry_quantiles": {str(q): float(np.quantile((w[:, 2] - t0) / span, q)) for q in (0.0, 0.1, 0.5, 0.9, 1.0)},
                           "mean_running_share": float(((w[:, 1] - w[:, 0]) / span).mean())}), flush=True)
         return
     eng.render()
