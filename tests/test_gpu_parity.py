@@ -590,6 +590,13 @@ def test_error_behaviour():
     assert eng.render().shape == (32, 32, 3)
     with pytest.raises(rt_amd.RtError):
         eng.setOption(engine.OPT_LEAF_SIZE, 99)
+    # tuning options refuse what the kernels cannot run with, and a refused value leaves the context usable
+    for opt, bad_value in ((engine.OPT_TAIL_TAPER, 99), (engine.OPT_TAIL_TAPER, 401), (engine.OPT_TAIL_SPLIT, 64),
+                           (engine.OPT_PRIMARY_CHUNK, 100), (engine.OPT_PRIMARY_CHUNK, 32), (engine.OPT_PRIMARY_WAVES, 0),
+                           (engine.OPT_QUEUE_WAVES, 33), (engine.OPT_QUEUE_THRESHOLD, 65)):
+        with pytest.raises(rt_amd.RtError):
+            eng.setOption(opt, bad_value)
+    assert eng.render().shape == (32, 32, 3)
     eng.close()
 
 
