@@ -378,7 +378,7 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_ra
         L.frame_id = c->frame_id;
     }
     L.stats = reinterpret_cast<unsigned long long *>(c->d_bands + 16);
-    if (render && c->d_wave_times && (size_t)L.grid_waves <= c->wave_times_cap) L.wave_times = c->d_wave_times;
+    if (kind != kLaunchRays && c->d_wave_times && (size_t)L.grid_waves <= c->wave_times_cap) L.wave_times = c->d_wave_times;
     if (render && c->d_ray_dump) {
         L.ray_dump = c->d_ray_dump;
         L.ray_dump_count = c->d_ray_dump_count;

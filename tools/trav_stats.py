@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--occ", type=int, default=None)
     ap.add_argument("--waves", type=int, default=None)
     ap.add_argument("--tail", type=int, default=None)
+    ap.add_argument("--primary-only", action="store_true", help="with --wave-times: the primary-ray kernel instead of the render")
     ap.add_argument("--wave-times", action="store_true", help="when each wave of the render ends (share of waves still running over time)")
     ap.add_argument("--queue-waves", type=lambda t: [int(x) for x in t.split(",")], default=[16])
     ap.add_argument("--replay", type=str, default=None, metavar="T1,T2,...",
@@ -90,8 +91,11 @@ def main():
         nw = 256 * 32
         wt = np.zeros(3 * nw, dtype=np.uint64)
         eng._check(eng._lib.rt_test_wave_times(eng._h, wt.ctypes.data_as(C.c_void_p), nw), "rt_test_wave_times")
-        eng.render()
-        eng.render()
+        for _ in range(2):
+            if args.primary_only:
+                eng.tracePrimary()
+            else:
+                eng.render()
         eng._check(eng._lib.rt_test_wave_times(eng._h, wt.ctypes.data_as(C.c_void_p), nw), "rt_test_wave_times")
         w = wt.reshape(-1, 3)
         w = w[w[:, 1] > 0].astype(np.float64)
