@@ -157,6 +157,7 @@ enum {
     RT_OPT_QUEUE_WAVES = 21,     /* rt_trace_rays*: most persistent waves per CU, 1..32 (default 24; a short array gets fewer) */
     RT_OPT_PRIMARY_WAVES = 22,   /* rt_trace_primary*: most persistent waves per CU, 1..32 (default 16; a 1080p frame gets 8) */
     RT_OPT_PRIMARY_CHUNK = 23,   /* rt_trace_primary*: pixel slots a wave takes per atomic, a multiple of 64 (default 256) */
+    RT_OPT_COLLAPSE = 25,        /* device tree: 0 = wide nodes by largest-area expansion, 1 = by least surface-area cost (dynamic programme) */
     RT_OPT_TAIL_TAPER = 24       /* rounds: sample boundary r at ns (1 - (1 - r/R)^(value/100)); 100 = equal shares, more = short last rounds */
 };
 int rt_set_option(rt_ctx *ctx, int option, int64_t value);
@@ -193,7 +194,7 @@ int rt_test_introsort(const float *key, int32_t *idx, int n);
 int rt_test_build_bvh(const rt_triangle148 *tris, int n, int64_t rand_calls_before, rt_bvh_node32 *out);
 /* The device layout alone (no GPU needed).  Sizes first (pass NULL buffers), then the copies:
  * wide_nodes: 128 bytes each; quant_nodes: 64 bytes each (same indices); prims: 48 bytes each (DFS leaf order); info[4] = {n_wide, n_prims,
- * depth, stack_entries}. */
+ * depth, stack_entries}.  topology: bit 0 = RT_OPT_TOPOLOGY, bit 1 = RT_OPT_COLLAPSE. */
 int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size,
                         int box_mode, int topology, void *wide_nodes, void *quant_nodes, void *prims, int32_t info[4]);
 

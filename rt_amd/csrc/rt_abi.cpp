@@ -41,6 +41,7 @@ struct rt_ctx {
     int queue_waves = 24;     // k_trace_queue: persistent waves per CU, at most
     int primary_waves = 16;   // primary rays: persistent waves per CU, at most
     int primary_chunk = 256;  // primary rays: pixel slots per band-counter atomic
+    int collapse = 1;         // how binary subtrees become wide nodes (wide_bvh.h)
     // analysis builds: rays recorded by the last render (rt_test_dump_rays)
     float *d_ray_dump = nullptr;
     unsigned long long *d_ray_dump_count = nullptr;
@@ -155,8 +156,8 @@ void free_scene(rt_ctx *c) {
 // device layout from the reference tree (topology 0) or from a re-built SAH tree over the same primitives
 // (topology 1); either way ties are broken by the DFS-leaf rank in the REFERENCE tree.
 bool make_device_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *ref_nodes, int m, int leaf_size,
-                        int box_mode, int topology, WideBvh &wide, std::string &err) {
-    if (topology == 0) return build_wide_bvh(tris, n, ref_nodes, m, leaf_size, box_mode, nullptr, wide, err);
+                        int box_mode, int topology, WideBvh &wide, std::string &err, int collapse = 0) {
+    if (topology == 0) return build_wide_bvh(tris, n, ref_nodes, m, leaf_size, box_mode, nullptr, wide, err, collapse);
     std::vector<int32_t> order;
     if (!dfs_leaf_order(ref_nodes, m, n, order, err)) return false;
     std::vector<int32_t> ref_rank(n);
@@ -164,13 +165,13 @@ bool make_device_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *
     std::vector<rt_bvh_node32> sah;
     build_sah_bvh(tris, n, sah);
     // the SAH nodes carry un-padded boxes: always re-fit + pad (box mode 0)
-    return build_wide_bvh(tris, n, sah.data(), (int)sah.size(), leaf_size, 0, ref_rank.data(), wide, err);
+    return build_wide_bvh(tris, n, sah.data(), (int)sah.size(), leaf_size, 0, ref_rank.data(), wide, err, collapse);
 }
 
 int upload_scene(rt_ctx *c) {
     std::string err;
     if (!make_device_layout(c->tris.data(), (int)c->tris.size(), c->bnodes.data(), (int)c->bnodes.size(), c->leaf_size,
-                            c->box_mode, c->topology, c->wide, err))
+                            c->box_mode, c->topology, c->wide, err, c->collapse))
         return fail(c, RT_E_ARG, "wide BVH: " + err);
     if ((size_t)c->wide.stack_entries * 64 * 4 > 64 * 1024) return fail(c, RT_E_LIMIT, "tree too deep for the LDS stack");
     if (c->wide.qnodes.size() > ((size_t)1 << 26)) // the kernels address quantised nodes by a 32-bit byte offset
@@ -692,6 +693,11 @@ int rt_set_option(rt_ctx *c, int option, int64_t value) {
         if (value < 1 || value > 63) return fail(c, RT_E_ARG, "rounds 1..63");
         c->tail_split = (int)value;
         return RT_OK;
+    case RT_OPT_COLLAPSE:
+        if (value != 0 && value != 1) return fail(c, RT_E_ARG, "collapse 0 or 1");
+        if (c->collapse != (int)value) c->scene_on_device = false;
+        c->collapse = (int)value;
+        return RT_OK;
     case RT_OPT_TAIL_TAPER:
         if (value < 100 || value > 400) return fail(c, RT_E_ARG, "taper 100..400 (percent)");
         c->tail_taper = (int)value;
@@ -727,6 +733,7 @@ int rt_get_option(rt_ctx *c, int option, int64_t *value) {
     case RT_OPT_SWAP_BATCH: *value = c->swap_batch; return RT_OK;
     case RT_OPT_TAIL_SPLIT: *value = c->tail_split; return RT_OK;
     case RT_OPT_TAIL_TAPER: *value = c->tail_taper; return RT_OK;
+    case RT_OPT_COLLAPSE: *value = c->collapse; return RT_OK;
     case RT_OPT_SEED_SALT: *value = (int64_t)c->seed_salt; return RT_OK;
     case RT_OPT_RAW_SUM: *value = c->raw_sum; return RT_OK;
     case RT_OPT_QUEUE_THRESHOLD: *value = c->queue_threshold; return RT_OK;
@@ -936,7 +943,8 @@ int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *
     if (!tris || !nodes || !info) return RT_E_ARG;
     WideBvh w;
     std::string err;
-    if (!make_device_layout(tris, n, nodes, m, leaf_size, box_mode, topology, w, err)) return RT_E_ARG;
+    if (topology < 0 || topology > 3) return RT_E_ARG; // bit 0: RT_OPT_TOPOLOGY, bit 1: RT_OPT_COLLAPSE
+    if (!make_device_layout(tris, n, nodes, m, leaf_size, box_mode, topology & 1, w, err, topology >> 1)) return RT_E_ARG;
     info[0] = (int32_t)w.nodes.size();
     info[1] = (int32_t)w.prims.size();
     info[2] = w.depth;

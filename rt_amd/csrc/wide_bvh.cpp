@@ -64,7 +64,7 @@ bool dfs_leaf_order(const rt_bvh_node32 *nodes, int m, int n, std::vector<int32_
 }
 
 bool build_wide_bvh(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size, int box_mode,
-                    const int32_t *ref_rank, WideBvh &out, std::string &err) {
+                    const int32_t *ref_rank, WideBvh &out, std::string &err, int collapse) {
     out = WideBvh();
     if (n <= 0 || m <= 0) {
         err = "empty scene";
@@ -91,6 +91,8 @@ bool build_wide_bvh(const rt_triangle148 *tris, int n, const rt_bvh_node32 *node
         int32_t phase;
     };
     std::vector<Frame> stk;
+    std::vector<int32_t> post; // every node after its children
+    post.reserve(m);
     stk.push_back({m - 1, 0});
     while (!stk.empty()) {
         Frame f = stk.back();
@@ -113,6 +115,7 @@ bool build_wide_bvh(const rt_triangle148 *tris, int n, const rt_bvh_node32 *node
                 order.push_back(nd.left);
                 I.count = 1;
                 prim_box_tight(tris[nd.left], I.mn, I.mx);
+                post.push_back(f.node);
             } else {
                 if (nd.left < 0 || nd.left >= m || nd.right < 0 || nd.right >= m) {
                     err = "child index out of range";
@@ -129,6 +132,7 @@ bool build_wide_bvh(const rt_triangle148 *tris, int n, const rt_bvh_node32 *node
                 I.mn[a] = std::min(L.mn[a], R.mn[a]);
                 I.mx[a] = std::max(L.mx[a], R.mx[a]);
             }
+            post.push_back(f.node);
         }
     }
     if ((int)order.size() != n) {
@@ -202,6 +206,77 @@ bool build_wide_bvh(const rt_triangle148 *tris, int n, const rt_bvh_node32 *node
         }
     };
 
+    // ---- collapse 1: cost[i-1] = least surface-area cost of the subtree of binary node b as at most i children of a
+    // wide node (i = 1..3).  One child is a leaf (subtrees of at most leaf_size primitives, always) or a wide node,
+    // whose own four slots are shared between b's two children in the cheapest way (left4 = the left child's share);
+    // with i > 1 slots b may also dissolve into use[i-1] of them, left[i-1] going to its left child.
+    const float kNodeCost = 1.0f, kPrimCost = 1.0f; // a node step and a primitive test cost about the same per lane
+    struct Dp {
+        float cost[3];
+        uint8_t use[3], left[3], left4;
+    };
+    std::vector<Dp> dp;
+    std::vector<uint8_t> leafy;
+    if (collapse == 1) {
+        dp.resize(m);
+        leafy.resize(m);
+        for (int32_t b : post) {
+            Dp &D = dp[b];
+            const float area = half_area(info[b]);
+            leafy[b] = nodes[b].left == nodes[b].right || info[b].count <= leaf_size;
+            if (leafy[b]) {
+                D.cost[0] = D.cost[1] = D.cost[2] = area * kPrimCost * (float)info[b].count;
+                D.use[0] = D.use[1] = D.use[2] = 1;
+                D.left[0] = D.left[1] = D.left[2] = D.left4 = 0;
+                continue;
+            }
+            const Dp &L = dp[nodes[b].left], &R = dp[nodes[b].right];
+            float dist[5];
+            uint8_t arg[5];
+            for (int j = 2; j <= 4; j++) { // b's subtree over exactly-at-most j slots, k of them to the left child
+                dist[j] = std::numeric_limits<float>::infinity();
+                arg[j] = 1;
+                for (int k = std::max(1, j - 3); k <= std::min(3, j - 1); k++) {
+                    const float c = L.cost[k - 1] + R.cost[j - k - 1];
+                    if (c < dist[j]) {
+                        dist[j] = c;
+                        arg[j] = (uint8_t)k;
+                    }
+                }
+            }
+            D.left4 = arg[4];
+            D.cost[0] = area * kNodeCost + dist[4];
+            D.use[0] = 1;
+            D.left[0] = 0;
+            for (int i = 2; i <= 3; i++) {
+                if (dist[i] < D.cost[i - 2]) {
+                    D.cost[i - 1] = dist[i];
+                    D.use[i - 1] = (uint8_t)i;
+                    D.left[i - 1] = arg[i];
+                } else { // one slot less was as cheap: the same choice
+                    D.cost[i - 1] = D.cost[i - 2];
+                    D.use[i - 1] = D.use[i - 2];
+                    D.left[i - 1] = D.left[i - 2];
+                }
+            }
+        }
+    }
+    // the children binary node b contributes when it may take up to i slots, in DFS order
+    struct Expand {
+        const std::vector<Dp> &dp;
+        const std::vector<uint8_t> &leafy;
+        const rt_bvh_node32 *nodes;
+        void run(int32_t b, int i, int32_t *slots, int &ns) const {
+            const Dp &D = dp[b];
+            if (leafy[b] || D.use[i - 1] <= 1) {
+                slots[ns++] = b;
+                return;
+            }
+            run(nodes[b].left, D.left[i - 1], slots, ns);
+            run(nodes[b].right, D.use[i - 1] - D.left[i - 1], slots, ns);
+        }
+    };
+
     // ---- pass 2: breadth-first collapse, largest half-area first ----
     struct Work {
         int32_t bnode; // binary subtree to expand into this wide node
@@ -221,6 +296,11 @@ bool build_wide_bvh(const rt_triangle148 *tris, int n, const rt_bvh_node32 *node
         const rt_bvh_node32 &b = nodes[wk.bnode];
         if (info[wk.bnode].count <= leaf_size || b.left == b.right) {
             slots[ns++] = wk.bnode; // whole (sub)scene fits one leaf: a node with a single leaf child
+        } else if (collapse == 1) {
+            const Expand ex{dp, leafy, nodes};
+            const int k = dp[wk.bnode].left4;
+            ex.run(b.left, k, slots, ns);
+            ex.run(b.right, 4 - k, slots, ns);
         } else {
             slots[ns++] = b.left;
             slots[ns++] = b.right;

@@ -25,8 +25,12 @@ struct WideBvh {
 // leaf_size: 1..kMaxLeafPrims primitives per leaf.  box_mode: 0 = re-fitted + one pad, 1 = reference boxes.
 // Returns false and fills err if the node array is not a tree over exactly the n primitives.
 // ref_rank: per primitive, its DFS-leaf rank in the reference tree (tie order); nullptr = the rank in `nodes` itself.
+// collapse: how binary subtrees become 4-wide nodes.  0 = expand the child with the largest half-area until four
+// slots are taken.  1 = the partition that minimises the surface-area cost of the wide tree (dynamic programme over the
+// binary tree, after Ylitie, Karras, Laine 2017, sec. 4.1).  Either way the result is a conservative hierarchy over the
+// same primitives in the same DFS order, so traced results cannot differ.
 bool build_wide_bvh(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size, int box_mode,
-                    const int32_t *ref_rank, WideBvh &out, std::string &err);
+                    const int32_t *ref_rank, WideBvh &out, std::string &err, int collapse = 0);
 
 // DFS (left first) leaf order of a binary tree: order[rank] = primitive.  Validates that `nodes` is a tree over
 // exactly the n primitives.

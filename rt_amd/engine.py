@@ -44,6 +44,7 @@ OPT_QUEUE_WAVES = 21
 OPT_PRIMARY_WAVES = 22
 OPT_PRIMARY_CHUNK = 23
 OPT_TAIL_TAPER = 24
+OPT_COLLAPSE = 25
 
 
 class RtStats(C.Structure):

@@ -137,6 +137,29 @@ def test_primary_launch_shapes(oracle, waves, chunk, nx, ny):
     eng.close()
 
 
+@pytest.mark.parametrize("scene,leaf", [("heightfield", 2), ("heightfield", 4), ("spheres", 2), ("spheres", 1)])
+def test_collapse_by_cost_same_results(oracle, scene, leaf):
+    """RT_OPT_COLLAPSE 1: wide nodes formed by least surface-area cost instead of largest-area expansion.  Another
+    conservative hierarchy over the same primitives: image, primary ids and t are the oracle's, bit for bit, and the
+    tree has no more nodes than the greedy one."""
+    tris = scenes.heightfield(40) if scene == "heightfield" else scenes.spheres_scene()
+    cam, nx, ny, ns, depth = scenes.BENCH_CAMERA, 93, 61, 3, 6
+    counts = []
+    for col in (0, 1):
+        eng = _engine(tris, nx, ny, ns, depth, cam, {engine.OPT_COLLAPSE: col, engine.OPT_LEAF_SIZE: leaf})
+        fb = eng.render()
+        counts.append(eng.last_stats.wide_nodes)
+        ids, ts = eng.tracePrimary()
+        nodes = eng.getBvhNodes()
+        ocam = oracle.camera(cam["lookfrom"], cam["lookat"], 40.0, nx / ny, cam["aperture"], cam["dist_to_focus"])
+        fb_o, cnt = oracle.render(tris, nodes, oracle.material_table(), ocam, nx, ny, ns, depth, mode=1)
+        ids_o, ts_o, _ = oracle.trace_primary(tris, nodes, ocam, nx, ny, mode=1, threads=8)
+        assert fb.tobytes() == fb_o.tobytes() and eng.last_stats.rays >= nx * ny
+        assert ids.tobytes() == ids_o.tobytes() and ts.tobytes() == ts_o.tobytes()
+        eng.close()
+    assert counts[1] <= counts[0]
+
+
 def test_trace_rays_incoherent(oracle):
     """Incoherent rays (bounce-like): random origins above the surface, random directions."""
     tris = scenes.heightfield(96)

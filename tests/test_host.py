@@ -152,7 +152,8 @@ def _py_closest(wide, prims, org, d):
     return best, best_t
 
 
-@pytest.mark.parametrize("leaf,box_mode,topology", [(1, 0, 0), (4, 0, 0), (8, 0, 0), (4, 1, 0), (2, 1, 0), (1, 0, 1), (4, 0, 1)])
+@pytest.mark.parametrize("leaf,box_mode,topology", [(1, 0, 0), (4, 0, 0), (8, 0, 0), (4, 1, 0), (2, 1, 0), (1, 0, 1), (4, 0, 1),
+                                                   (2, 0, 3), (1, 0, 2), (4, 1, 2), (8, 0, 3)])  # topology bit 1: collapse by cost
 def test_wide_layout_covers_and_hits(oracle, leaf, box_mode, topology):
     for tris, lo, hi in ((scenes.heightfield(14), (-9, 3, -9), (9, 8, 9)), (scenes.spheres_scene(), (-8, 0.5, -8), (8, 6, 8))):
         nodes = engine.host_build_bvh(tris)
@@ -162,7 +163,7 @@ def test_wide_layout_covers_and_hits(oracle, leaf, box_mode, topology):
         # tie order = DFS leaf rank in the REFERENCE tree; with the reference topology it is also the device order
         rank = oracle.dfs_rank(nodes, n)
         assert (rank[prims["orig"]] == prims["ref_rank"]).all()
-        if topology == 0:
+        if topology & 1 == 0:
             assert (prims["ref_rank"] == np.arange(n)).all()
         # every leaf range is referenced exactly once; every node but the root exactly once
         seen = np.zeros(n, dtype=np.int32)
@@ -191,6 +192,30 @@ def test_wide_layout_covers_and_hits(oracle, leaf, box_mode, topology):
             assert got == (i if h else -1), (org, d, i, got, t, gt)
             hits += h
         assert hits > 10
+
+
+def test_collapse_by_cost_is_no_worse_than_greedy():
+    """RT_OPT_COLLAPSE 1 minimises the summed surface area of the wide tree's inner nodes (the expected number of node
+    steps of a random ray) for the given binary tree: it can never come out above the greedy collapse, and on these
+    scenes it needs fewer nodes."""
+    def inner_area(wide):
+        area = 0.0
+        for nd in wide:
+            for s in range(4):
+                ch = int(nd["child"][s])
+                if ch != 0xFFFFFFFF and not ch & 0x80000000:
+                    d = nd["plane"][3:6, s].astype(np.float64) - nd["plane"][0:3, s].astype(np.float64)
+                    area += d[0] * d[1] + d[1] * d[2] + d[2] * d[0]
+        return area
+
+    for tris in (scenes.heightfield(30), scenes.spheres_scene()):
+        nodes = engine.host_build_bvh(tris)
+        for topo in (0, 1):
+            for leaf in (1, 2, 4):
+                greedy = engine.host_wide_layout(tris, nodes, leaf, 0, topology=topo)[0]
+                cost = engine.host_wide_layout(tris, nodes, leaf, 0, topology=topo | 2)[0]
+                assert inner_area(cost) <= inner_area(greedy) * (1 + 1e-6)
+                assert cost.shape[0] <= greedy.shape[0]
 
 
 def test_quantized_nodes_are_conservative():

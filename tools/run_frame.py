@@ -39,7 +39,8 @@ def main():
     ap.add_argument("--shade", type=ints, default=[32])
     ap.add_argument("--swap", type=ints, default=[8])
     ap.add_argument("--tail", type=ints, default=[8])
-    ap.add_argument("--taper", type=ints, default=[100])
+    ap.add_argument("--taper", type=ints, default=[150])
+    ap.add_argument("--collapse", type=ints, default=[1])
     ap.add_argument("--pwaves", type=ints, default=[16], help="primary rays: waves per CU")
     ap.add_argument("--pchunk", type=ints, default=[256], help="primary rays: slots per atomic")
     args = ap.parse_args()
@@ -49,7 +50,7 @@ def main():
     eng.setMaxDepth(args.depth)
     eng.setCamera(**scenes.BENCH_CAMERA)
     nodes = None
-    for leaf, bm, kv, th, wv, ld, fm, lb, oc, tp, sb, wb, ts, tap in itertools.product(args.leaf, args.box_mode, args.kernel, args.threshold, args.waves, args.lds, args.fmt, args.batch, args.occ, args.topo, args.shade, args.swap, args.tail, args.taper):
+    for leaf, bm, kv, th, wv, ld, fm, lb, oc, tp, sb, wb, ts, tap, col in itertools.product(args.leaf, args.box_mode, args.kernel, args.threshold, args.waves, args.lds, args.fmt, args.batch, args.occ, args.topo, args.shade, args.swap, args.tail, args.taper, args.collapse):
         eng.setOption(E.OPT_LEAF_SIZE, leaf)
         eng.setOption(E.OPT_BOX_MODE, bm)
         eng.setOption(E.OPT_KERNEL, kv)
@@ -64,12 +65,13 @@ def main():
         eng.setOption(E.OPT_SWAP_BATCH, wb)
         eng.setOption(E.OPT_TAIL_SPLIT, ts)
         eng.setOption(E.OPT_TAIL_TAPER, tap)
+        eng.setOption(E.OPT_COLLAPSE, col)
         if nodes is None:
             eng.buildBvh()
             nodes = eng.getBvhNodes()
         else:
             eng.setBvhNodes(nodes)
-        out = {"leaf": leaf, "box_mode": bm, "kernel": kv, "thr": th, "waves": wv, "lds": ld, "fmt": fm, "batch": lb, "occ": oc, "topo": tp, "shade": sb, "swap": wb, "tail": ts, "taper": tap}
+        out = {"leaf": leaf, "box_mode": bm, "kernel": kv, "thr": th, "waves": wv, "lds": ld, "fmt": fm, "batch": lb, "occ": oc, "topo": tp, "shade": sb, "swap": wb, "tail": ts, "taper": tap, "collapse": col}
         best = None
         for _ in range(args.frames):
             eng.render()
