@@ -50,6 +50,7 @@ def main():
     eng.setMaxDepth(args.depth)
     eng.setCamera(**scenes.BENCH_CAMERA)
     nodes = None
+    warmed = False
     for leaf, bm, kv, th, wv, ld, fm, lb, oc, tp, sb, wb, ts, tap, col in itertools.product(args.leaf, args.box_mode, args.kernel, args.threshold, args.waves, args.lds, args.fmt, args.batch, args.occ, args.topo, args.shade, args.swap, args.tail, args.taper, args.collapse):
         eng.setOption(E.OPT_LEAF_SIZE, leaf)
         eng.setOption(E.OPT_BOX_MODE, bm)
@@ -73,6 +74,10 @@ def main():
             eng.setBvhNodes(nodes)
         out = {"leaf": leaf, "box_mode": bm, "kernel": kv, "thr": th, "waves": wv, "lds": ld, "fmt": fm, "batch": lb, "occ": oc, "topo": tp, "shade": sb, "swap": wb, "tail": ts, "taper": tap, "collapse": col}
         best = None
+        if args.frames and not warmed:  # the first frames of a process run slow (clocks, first touches): not measured
+            eng.render()
+            eng.render()
+            warmed = True
         for _ in range(args.frames):
             eng.render()
             ms = eng.last_stats.kernel_ms
