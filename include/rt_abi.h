@@ -144,7 +144,7 @@ enum {
                                     rt_get_bvh_nodes always returns the reference's tree. */
     RT_OPT_SHADE_BATCH = 15,     /* kernel 3: lanes with shading work queued that end a traversal phase */
     RT_OPT_SWAP_BATCH = 16,      /* kernel 3: lanes waiting to exchange their two paths that trigger the exchange */
-    RT_OPT_TAIL_SPLIT = 17,      /* kernel 1/2 render: the frame is walked in this many rounds (1..63, at most ns; default 8),
+    RT_OPT_TAIL_SPLIT = 17,      /* kernel 1/2 render: the frame is walked in this many rounds (1..63, at most ns; default 0 = 2..8 by pixels per lane),
                                     each running ns/rounds samples of every pixel and handing the pixel's state on to
                                     whichever lane takes it next round, so that the frame ends on fractions of a pixel
                                     instead of whole pixels; 1 = off.  Same image either way. */

@@ -614,7 +614,7 @@ def test_error_behaviour():
     with pytest.raises(rt_amd.RtError):
         eng.setOption(engine.OPT_LEAF_SIZE, 99)
     # tuning options refuse what the kernels cannot run with, and a refused value leaves the context usable
-    for opt, bad_value in ((engine.OPT_TAIL_TAPER, 99), (engine.OPT_TAIL_TAPER, 401), (engine.OPT_TAIL_SPLIT, 64),
+    for opt, bad_value in ((engine.OPT_TAIL_TAPER, 99), (engine.OPT_TAIL_TAPER, 401), (engine.OPT_TAIL_SPLIT, 64), (engine.OPT_TAIL_SPLIT, -1),
                            (engine.OPT_PRIMARY_CHUNK, 100), (engine.OPT_PRIMARY_CHUNK, 32), (engine.OPT_PRIMARY_WAVES, 0),
                            (engine.OPT_QUEUE_WAVES, 33), (engine.OPT_QUEUE_THRESHOLD, 65)):
         with pytest.raises(rt_amd.RtError):

@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--topo", type=ints, default=[1])
     ap.add_argument("--shade", type=ints, default=[32])
     ap.add_argument("--swap", type=ints, default=[8])
-    ap.add_argument("--tail", type=ints, default=[8])
+    ap.add_argument("--tail", type=ints, default=[0])
     ap.add_argument("--taper", type=ints, default=[150])
     ap.add_argument("--collapse", type=ints, default=[1])
     ap.add_argument("--pwaves", type=ints, default=[16], help="primary rays: waves per CU")
