@@ -1282,6 +1282,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
         // The refill threshold is a share of the lanes that still have work: at the end of a frame retired lanes pile
         // up, and a fixed count would send the wave through the whole refill phase for every single ray that ends.
         const int thr_eff = (P.threshold * (int)__popcll(live_m) + 63) >> 6;
+        const int batch_eff = (P.leaf_batch * (int)__popcll(live_m) + 63) >> 6; // the leaf batch likewise
         if (ring_on && ballot(tracing) == 0ull) {
             // every live lane waits for a ring item: nothing to do but poll.  Sleep between polls (127 x 64 clocks,
             // ~3.5 us) so that the waiting wave leaves the SIMD's issue slots to the waves that still produce.
@@ -1359,7 +1360,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                 const unsigned long long leaf_mask = ballot(want_leaf);
                 if (leaf_mask != 0ull) {
                     const unsigned long long node_mask = ballot(!(T.cur & kLeafBit));
-                    if (node_mask == 0ull || (int)__popcll(leaf_mask) >= P.leaf_batch) {
+                    if (node_mask == 0ull || (int)__popcll(leaf_mask) >= batch_eff) {
                         RT_STAT(kStatLeafFires, 1);
                         RT_STAT(kStatLeafLanes, __popcll(leaf_mask));
 #ifdef RT_TRAV_STATS
@@ -1478,7 +1479,9 @@ __global__ void __launch_bounds__(64, 6) k_trace_queue(KernelScene S, PersistArg
             const unsigned long long leaf_mask = ballot(want_leaf);
             if (leaf_mask != 0ull) {
                 const unsigned long long node_mask = ballot(tracing && !(T.cur & kLeafBit));
-                if (node_mask == 0ull || (int)__popcll(leaf_mask) >= P.leaf_batch)
+                // once the rays have run out the batch is a share of the lanes still tracing
+                const int batch_eff = exhausted ? (P.leaf_batch * (int)__popcll(act) + 63) >> 6 : P.leaf_batch;
+                if (node_mask == 0ull || (int)__popcll(leaf_mask) >= batch_eff)
                     leaf_fire(T, S, cur, want_leaf, leaf_mask, lds_addr(s_child));
             }
             if (tracing && T.cur == RT_REF_NONE && T.pend == RT_REF_NONE) {
