@@ -1755,7 +1755,7 @@ hipError_t launch_trace_queue(const KernelScene &S, const PersistLaunch &L, cons
     if (n == 0) return hipSuccess;
     if (L.lds_entries < 1 || L.grid_waves < 1) return hipErrorInvalidValue;
     const size_t lds = (size_t)L.lds_entries * 64 * sizeof(uint32_t);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    if (lds > 62 * 1024) return hipErrorInvalidValue; // 64 KB per workgroup, less the static child table / leaf exchange
     PersistArgs P = {};
     P.spill = L.spill;
     P.lds_entries = L.lds_entries;
@@ -1791,7 +1791,7 @@ hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &
     if (F.n_local_tiles <= 0) return hipSuccess;
     if (L.lds_entries < 1 || L.grid_waves < 1 || F.nx > 65535 || F.ny > 65535) return hipErrorInvalidValue; // pij packing
     size_t lds = (size_t)L.lds_entries * 64 * sizeof(uint32_t);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    if (lds > 62 * 1024) return hipErrorInvalidValue; // 64 KB per workgroup, less the static child table / leaf exchange
     PersistArgs P;
     P.band_counters = L.band_counters;
     P.spill = L.spill;

@@ -652,7 +652,7 @@ int rt_set_option(rt_ctx *c, int option, int64_t value) {
         c->waves_per_cu = (int)value;
         return RT_OK;
     case RT_OPT_LDS_STACK:
-        if (value < 1 || value > 256) return fail(c, RT_E_ARG, "LDS stack entries 1..256");
+        if (value < 1 || value > 248) return fail(c, RT_E_ARG, "LDS stack entries 1..248");
         c->lds_stack = (int)value;
         return RT_OK;
     case RT_OPT_NODE_FORMAT:
