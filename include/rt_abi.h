@@ -201,6 +201,8 @@ int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *
 /* The tile-sharding rule alone (no GPU needed): owner[j*nx+i] = rank that renders pixel (i, j) when the frame
  * is split over `world` contexts (RT_OPT_SHARD_RANK / RT_OPT_SHARD_WORLD). */
 int rt_test_tile_owner(int nx, int ny, int world, int32_t *owner);
+/* The kernels' division of a tile index by tiles_x (multiply-high and shifts, no GPU needed): q[i] = n[i] / d. */
+int rt_test_fastdiv(uint32_t d, const uint32_t *n, int count, uint32_t *q);
 
 /* The library's sine / cosine (binary64 range reduction + Taylor, rounded once to float): what the
  * host-side scene code (rt_scene.hpp, scene_graph.py) uses for glm::rotate so that both produce the same matrices. */

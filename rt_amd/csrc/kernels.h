@@ -19,10 +19,36 @@ struct KernelScene {
     const DevTex *tex;   // RT_TEX_NUM entries (only read when uv != nullptr)
 };
 
+// n / d for any 32-bit n by a multiply-high and two shifts (Granlund & Montgomery's round-up method): hipcc expands a
+// division by a run-time value into ~25 vector instructions, and the kernels divide a tile index by tiles_x for
+// every pixel a lane takes.  shift == ~0u stands for d == 1.
+struct FastDiv {
+    uint32_t mul, shift;
+};
+inline FastDiv fastdiv_make(uint32_t d) {
+    FastDiv f;
+    if (d <= 1u) {
+        f.mul = 0u;
+        f.shift = ~0u;
+        return f;
+    }
+    uint32_t l = 0;
+    while ((1ull << l) < d) l++; // ceil(log2 d), >= 1
+    f.mul = (uint32_t)((((1ull << 32) * ((1ull << l) - d)) / d) + 1ull);
+    f.shift = l - 1u;
+    return f;
+}
+inline uint32_t fastdiv_host(const FastDiv &f, uint32_t n) {
+    if (f.shift == ~0u) return n;
+    const uint32_t t = (uint32_t)(((uint64_t)f.mul * n) >> 32);
+    return (t + ((n - t) >> 1)) >> f.shift;
+}
+
 struct KernelFrame {
     DevCamera cam;
     int nx, ny, ns, max_depth;
     int tiles_x, tiles_y;
+    FastDiv div_tiles_x; // fastdiv_make(tiles_x)
     int n_local_tiles; // tiles this context renders = grid size
     int shard_rank, shard_world;
     unsigned long long *ray_counter;

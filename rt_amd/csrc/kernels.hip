@@ -472,8 +472,13 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
 // rays 0.49 instead of 0.54 ms, the 64 spp frame 46.6 instead of 44.7 ms; with stealing spread over all bands
 // 0.50 instead of 0.55 ms and 42.2 instead of 41.7 ms.)
 __device__ __forceinline__ void tile_xy(const KernelFrame &F, uint32_t g, int &tx, int &ty) {
-    tx = (int)(g % (uint32_t)F.tiles_x);
-    ty = (int)(g / (uint32_t)F.tiles_x);
+    uint32_t q = g;
+    if (F.div_tiles_x.shift != ~0u) {
+        const uint32_t t = __umulhi(F.div_tiles_x.mul, g);
+        q = (t + ((g - t) >> 1)) >> F.div_tiles_x.shift;
+    }
+    ty = (int)q;
+    tx = (int)(g - q * (uint32_t)F.tiles_x);
 }
 
 __device__ __forceinline__ bool tile_pixel(const KernelFrame &F, int &i, int &j) {

@@ -264,6 +264,7 @@ void fill_frame(rt_ctx *c, KernelFrame &F) {
     F.max_depth = c->max_depth;
     F.tiles_x = (c->nx + 7) / 8;
     F.tiles_y = (c->ny + 7) / 8;
+    F.div_tiles_x = fastdiv_make((uint32_t)F.tiles_x);
     long total = (long)F.tiles_x * F.tiles_y;
     F.shard_rank = c->shard_rank;
     F.shard_world = c->shard_world;
@@ -1066,6 +1067,13 @@ int rt_test_sincosf(float x, float *s, float *c) {
     sincos_sh((double)x, sd, cd);
     *s = (float)sd;
     *c = (float)cd;
+    return RT_OK;
+}
+
+int rt_test_fastdiv(uint32_t d, const uint32_t *n, int count, uint32_t *q) {
+    if (d == 0 || !n || !q || count < 0) return RT_E_ARG;
+    const FastDiv f = fastdiv_make(d);
+    for (int i = 0; i < count; i++) q[i] = fastdiv_host(f, n[i]);
     return RT_OK;
 }
 

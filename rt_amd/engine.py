@@ -70,7 +70,7 @@ ABI_SYMBOLS = [
     "rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_resize", "rt_set_scene", "rt_build_bvh",
     "rt_set_bvh_nodes", "rt_get_bvh_nodes", "rt_default_materials", "rt_set_materials", "rt_set_camera",
     "rt_set_option", "rt_get_option", "rt_render", "rt_render_device", "rt_trace_primary", "rt_trace_rays",
-    "rt_write_ppm", "rt_test_glibc_rand", "rt_test_introsort", "rt_test_build_bvh", "rt_test_wide_layout", "rt_test_tile_owner",
+    "rt_write_ppm", "rt_test_glibc_rand", "rt_test_introsort", "rt_test_build_bvh", "rt_test_wide_layout", "rt_test_tile_owner", "rt_test_fastdiv",
     "rt_test_trav_stats", "rt_test_sincosf", "rt_set_texture", "rt_trace_rays_device", "rt_test_dump_rays", "rt_test_wave_times",
     "rt_test_trace_dumped",
 ]
@@ -114,6 +114,7 @@ def load_library(path: str = LIB_PATH):
     lib.rt_test_introsort.argtypes = [vp, vp, C.c_int]
     lib.rt_test_build_bvh.argtypes = [vp, C.c_int, C.c_int64, vp]
     lib.rt_test_tile_owner.argtypes = [C.c_int, C.c_int, C.c_int, vp]
+    lib.rt_test_fastdiv.argtypes = [C.c_uint32, vp, C.c_int, vp]
     lib.rt_test_wide_layout.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     for name in ABI_SYMBOLS:
         if name != "rt_last_error":

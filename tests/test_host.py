@@ -194,6 +194,21 @@ def test_wide_layout_covers_and_hits(oracle, leaf, box_mode, topology):
         assert hits > 10
 
 
+def test_fastdiv_is_exact():
+    """The kernels divide tile indices by tiles_x with a multiply-high and two shifts: exact for every 32-bit
+    dividend, for the divisors a frame can have (1..8192) and awkward ones beyond."""
+    import ctypes as C
+
+    lib = engine.load_library()
+    rs = np.random.RandomState(5)
+    n = np.concatenate([np.arange(0, 70000, dtype=np.uint32), rs.randint(0, 2**32, size=200000, dtype=np.uint64).astype(np.uint32),
+                        np.array([2**32 - 1, 2**31, 2**31 - 1, 2**26, 2**26 - 1], dtype=np.uint32)])
+    q = np.zeros_like(n)
+    for d in list(range(1, 300)) + [1023, 1024, 1025, 4095, 4096, 8191, 8192, 65535, 65536, 2**20 + 7, 2**31 - 1, 2**31, 2**32 - 1]:
+        assert lib.rt_test_fastdiv(C.c_uint32(d), n.ctypes.data_as(C.c_void_p), n.shape[0], q.ctypes.data_as(C.c_void_p)) == 0
+        assert (q == n // np.uint32(d)).all(), d
+
+
 def test_collapse_by_cost_is_no_worse_than_greedy():
     """RT_OPT_COLLAPSE 1 minimises the summed surface area of the wide tree's inner nodes (the expected number of node
     steps of a random ray) for the given binary tree: it can never come out above the greedy collapse, and on these
