@@ -56,6 +56,19 @@ __device__ __forceinline__ void clip_color(V3 &v) {                             
 }
 #define RT_REF_PI 3.1415926 /* vec3.h:16 */
 
+// (float)((double)c / 3.1415926), bit for bit, mostly without the division.  q' = RN(c * RN(1 / P)) lies within 3 ulp
+// (double) of Q = RN(c / P): relative errors 2^-53 (reciprocal) + 2^-53 (product) against 2^-53 (quotient).  Rounded to
+// float the two differ only if a float rounding midpoint lies between them, i.e. if the 29 mantissa bits of q' below
+// float precision are within 3 of 0x10000000; then, and for c too small for a normal float result (or not positive,
+// or NaN), the division runs.  One lane in 2^25 takes it.
+__device__ __forceinline__ float div_ref_pi(float c) {
+    const double q = (double)c * (1.0 / RT_REF_PI);
+    const uint32_t low = (uint32_t)(unsigned long long)__double_as_longlong(q) & 0x1FFFFFFFu;
+    const bool near_midpoint = (low - 0x0FFFFFF8u) <= 16u; // |low - 0x10000000| <= 8
+    if (__builtin_expect(near_midpoint || !(c >= 1e-30f), 0)) return (float)((double)c / RT_REF_PI);
+    return (float)q;
+}
+
 // ------------------------------------------------------------------ closest hit
 struct Ray {
     V3 o, d;
@@ -280,7 +293,7 @@ __device__ __forceinline__ V3 cosine_generate(const Onb &b, Rng &g) {
 }
 __device__ __forceinline__ float cosine_value(const Onb &b, V3 dir) {
     float c = vdot(vunit(dir), b.w);
-    return (float)(c > 0 ? (double)c / RT_REF_PI : 0.0);
+    return c > 0 ? div_ref_pi(c) : 0.0f;
 }
 __device__ __forceinline__ V3 ball_sample(Rng &g) { // random_in_unit_sphere, material.h:27-33
     V3 p;
@@ -409,7 +422,7 @@ __device__ __forceinline__ bool shade_bounce(const KernelScene &S, const Hit &h,
         }
         float cosine = vdot(n, vunit(dir)); // lambertian::scatter_pdf
         if ((double)cosine < 0.0) cosine = 0.0f;
-        float spdf = (float)((double)cosine / 3.1415926);
+        float spdf = div_ref_pi(cosine);
         thr = vmul(thr, vdiv(vscl(spdf, atten), pdf));
         cur.o = p;
         cur.d = dir;

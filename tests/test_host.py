@@ -194,6 +194,30 @@ def test_wide_layout_covers_and_hits(oracle, leaf, box_mode, topology):
         assert hits > 10
 
 
+def test_division_by_pi_shortcut_is_exact():
+    """kernels.hip div_ref_pi: (float)((double)c / 3.1415926) computed as (float)((double)c * (1 / 3.1415926)) unless the
+    product's 29 bits below float precision sit within 8 of a rounding midpoint.  The claim behind it, checked on 40 M
+    floats (dense near 0, 1 and the powers of two, random elsewhere): outside that guard the two agree bit for bit."""
+    P = np.float64(3.1415926)
+    r = np.float64(1.0) / P
+    rs = np.random.RandomState(11)
+    chunks = [rs.uniform(0, 1, size=10_000_000).astype(np.float32) for _ in range(3)]
+    chunks.append(np.exp2(rs.uniform(-90, 0, size=10_000_000)).astype(np.float32))
+    edge = np.concatenate([np.float32(2.0) ** np.arange(-90, 1, dtype=np.float32) * f for f in (np.float32(1), np.nextafter(np.float32(1), np.float32(2)), np.nextafter(np.float32(1), np.float32(0)))])
+    chunks.append(edge.astype(np.float32))
+    guarded = 0
+    for c in chunks:
+        c = c[c >= np.float32(1e-30)]
+        q = c.astype(np.float64) * r
+        low = q.view(np.uint64) & np.uint64(0x1FFFFFFF)
+        risky = np.abs(low.astype(np.int64) - 0x10000000) <= 8
+        guarded += int(risky.sum())
+        fast = q.astype(np.float32)
+        exact = (c.astype(np.float64) / P).astype(np.float32)
+        assert (fast[~risky].view(np.uint32) == exact[~risky].view(np.uint32)).all()
+    assert guarded < 100  # the guard is rare: ~17 in 2^29
+
+
 def test_fastdiv_is_exact():
     """The kernels divide tile indices by tiles_x with a multiply-high and two shifts: exact for every 32-bit
     dividend, for the divisors a frame can have (1..8192) and awkward ones beyond."""
