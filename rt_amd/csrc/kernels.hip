@@ -1209,6 +1209,8 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
             st_sc1(sp + 9, __float_as_uint(col.z));
             st_sc1(sp + 10, (uint32_t)k);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every store of the record has left before the flag goes
+            // (merging this drain with the wait of the polls further down -- one round trip instead of two -- was measured:
+            // 39.3 vs 38.4 ms; the flag reaches its reader later and every refill pays the drain)
             st_sc1(P.round_flag + my_slot, P.frame_id * 64u + (slot_round >> 26) + 1u); // next round's tag
             has_pixel = false;
         }
