@@ -157,8 +157,8 @@ enum {
     RT_OPT_QUEUE_WAVES = 21,     /* rt_trace_rays*: most persistent waves per CU, 1..32 (default 24; a short array gets fewer) */
     RT_OPT_PRIMARY_WAVES = 22,   /* rt_trace_primary*: most persistent waves per CU, 1..32 (default 16; a 1080p frame gets 8) */
     RT_OPT_PRIMARY_CHUNK = 23,   /* rt_trace_primary*: pixel slots a wave takes per atomic, a multiple of 64 (default 256) */
-    RT_OPT_COLLAPSE = 25,        /* device tree: 0 = wide nodes by largest-area expansion, 1 = by least surface-area cost (dynamic programme) */
-    RT_OPT_TAIL_TAPER = 24       /* rounds: sample boundary r at ns (1 - (1 - r/R)^(value/100)); 100 = equal shares, more = short last rounds */
+    RT_OPT_TAIL_TAPER = 24,      /* rounds: sample boundary r at ns (1 - (1 - r/R)^(value/100)); 100 = equal shares, more = short last rounds (default 150) */
+    RT_OPT_COLLAPSE = 25         /* device tree: 0 = wide nodes by largest-area expansion, 1 = by least surface-area cost (dynamic programme; default) */
 };
 int rt_set_option(rt_ctx *ctx, int option, int64_t value);
 int rt_get_option(rt_ctx *ctx, int option, int64_t *value);
