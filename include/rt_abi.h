@@ -107,8 +107,9 @@ int rt_get_bvh_nodes(rt_ctx *ctx, rt_bvh_node32 *out, int cap, int *m);
 
 /* One texture object (Texture::getTexture -> cudaCreateTextureObject, src/cxx/texture.cpp:45-86): RGBA8 texels, w*h*4
  * bytes, row 0 first, copied during the call.  Sampled as the reference's descriptor says: normalised coordinates,
- * wrap addressing, linear filtering, channels as byte/255 (utilities.cu:4-9); only a lambertian triangle with
- * texIdx != -1 reads it (material.h:100-106).  Image decoding stays with the caller (the reference uses stb). */
+ * wrap addressing, linear filtering, channels as byte/255 (utilities.cu:4-9); a lambertian or a diffusive_light
+ * triangle with texIdx != -1 reads it (material.h:100-106, 140-146; metal and dielectric ignore it).  Image decoding
+ * stays with the caller (the reference uses stb). */
 int rt_set_texture(rt_ctx *ctx, int index, const uint8_t *rgba8, int w, int h);
 
 /* material_init + rand_init (pbrt_engine.cu:25-47,597-601) as a host-side table. */

@@ -701,8 +701,10 @@ V path_color(const Scene &sc, const o_mat *mats, int max_depth, int mode, const 
                     sp.d = refracted;
                 thr = mul(thr, mk(1.0f, 1.0f, 1.0f));
                 cur = sp;
-            } else { /* diffusive_light, material.h:137-148: scatter() false, attenuation = albedo */
-                thr = mul(thr, alb);
+            } else { /* diffusive_light, material.h:137-148: scatter() false; attenuation = albedo, or the texture
+                      * when the hit triangle names one (:140-146), multiplied in at pbrt_engine.cu:544 */
+                V atten = rec.tex == -1 ? alb : tex_fetch(rec.tex, rec.u, rec.v);
+                thr = mul(thr, atten);
                 break;
             }
         } else { /* sky, pbrt_engine.cu:554-558 */

@@ -1,6 +1,7 @@
 // bvh_build.cpp -- see bvh_build.h.  Host code; compiled with -ffp-contract=off.
 #include "bvh_build.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -294,9 +295,8 @@ struct Builder {
             const int64_t lcalls = calls->get(l);
             const int64_t rbase = base + 2 * (int64_t)l - 1;
             if (depth < par_depth) {
-                std::thread left([=]() { go(m, m + l, call + 1, base, depth + 1, calls); });
-                go(m + l, n, call + 1 + lcalls, rbase, depth + 1, calls);
-                left.join();
+                fork_join([=]() { go(m, m + l, call + 1, base, depth + 1, calls); },
+                          [=]() { go(m + l, n, call + 1 + lcalls, rbase, depth + 1, calls); });
             } else {
                 go(m, m + l, call + 1, base, depth + 1, calls);
                 go(m + l, n, call + 1 + lcalls, rbase, depth + 1, calls);
@@ -341,7 +341,8 @@ void build_binary_bvh(const rt_triangle148 *tris, int n, int64_t rand_calls_befo
     out.resize(2 * (size_t)n - 1);
     b.out = out.data();
     b.par_depth = n >= (1 << 15) && std::thread::hardware_concurrency() > 1 ? 4 : 0; // 16 concurrent subtrees
-    if (const char *e = std::getenv("RT_BUILD_PAR_DEPTH")) b.par_depth = std::atoi(e);
+    if (const char *e = std::getenv("RT_BUILD_PAR_DEPTH")) // 2^depth threads: held to 0..6
+        b.par_depth = std::max(0, std::min(6, std::atoi(e)));
     b.go(0, n, 0, 0, 0, &calls);
 }
 

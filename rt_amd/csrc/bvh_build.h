@@ -10,6 +10,8 @@
 //     keys shapes the tree (ties are common: whole columns of a grid mesh share one min().x).
 #pragma once
 #include <cstdint>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt_abi.h"
@@ -33,6 +35,22 @@ void introsort_by_key(const float *key, int32_t *idx, int n);
 void prim_box_padded(const rt_triangle148 &t, float mn[3], float mx[3]);
 // Tight bounds (no pad).
 void prim_box_tight(const rt_triangle148 &t, float mn[3], float mx[3]);
+
+// Runs `left` on a thread of its own while the caller runs `right`; when the thread cannot be created (std::thread
+// throws std::system_error when the process is out of threads) `left` runs on the caller instead.  The builders'
+// recursions allocate nothing, so nothing else can throw between the spawn and the join.
+template <class L, class R> inline void fork_join(L left, R right) {
+    std::thread th;
+    bool spawned = false;
+    try {
+        th = std::thread(left);
+        spawned = true;
+    } catch (const std::system_error &) {
+    }
+    if (!spawned) left();
+    right();
+    if (spawned) th.join();
+}
 
 // Builds the post-order node array (root last).  rand_calls_before advances the generator first.
 void build_binary_bvh(const rt_triangle148 *tris, int n, int64_t rand_calls_before, std::vector<rt_bvh_node32> &out);

@@ -351,7 +351,8 @@ __device__ __forceinline__ V3 tex_fetch(const DevTex &T, float u, float v) {
     return c;
 }
 
-// lambertian::scatter's attenuation for a textured triangle (material.h:100-106): the hit record's (u, v) are the
+// lambertian::scatter's and diffusive_light::scatter's attenuation for a textured triangle (material.h:100-106,
+// 140-146; metal and dielectric never read the texture): the hit record's (u, v) are the
 // barycentric blend of the vertices' texture coordinates (setUV, triangle.h:113-118, with 1.0 - x - y in double).
 // The barycentrics are recomputed here with the arithmetic of prim_test: same inputs, same bits.
 __device__ __forceinline__ V3 textured_albedo(const KernelScene &S, int rank, const Ray &r, V3 alb) {
@@ -464,8 +465,10 @@ __device__ __forceinline__ bool shade_bounce(const KernelScene &S, const Hit &h,
         cur.o = p;
         cur.d = dir;
         return true;
-    } else { // diffusive_light, material.h:137-148 -> pbrt_engine.cu:544-545
-        thr = vmul(thr, alb);
+    } else { // diffusive_light, material.h:137-148 -> pbrt_engine.cu:544-545; a textured light triangle emits its texture
+        V3 atten = alb;
+        if (TEX && S.uv != nullptr && shape == 0) atten = textured_albedo(S, h.rank, cur, alb);
+        thr = vmul(thr, atten);
         return false;
     }
 }

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -100,6 +101,15 @@ int fail(rt_ctx *c, int code, const std::string &msg) {
             return fail(c, RT_E_HIP, buf_);                                                                            \
         }                                                                                                              \
     } while (0)
+
+// Nothing may throw across the C boundary (rt_abi.h): the host builders allocate vectors of many GB (bad_alloc) and
+// every entry point that reaches them runs between these two.
+#define RT_TRY try {
+#define RT_CATCH(c)                                                                                                    \
+    }                                                                                                                  \
+    catch (const std::bad_alloc &) { return fail(c, RT_E_LIMIT, "out of host memory"); }                               \
+    catch (const std::exception &e_) { return fail(c, RT_E_ARG, std::string("exception: ") + e_.what()); }             \
+    catch (...) { return fail(c, RT_E_ARG, "unknown exception"); }
 
 struct F3 {
     float x, y, z;
@@ -468,11 +478,12 @@ int rt_create(rt_ctx **out, int device_id) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return RT_E_HIP; // no CPU fallback
     if (device_id < 0 || device_id >= count) return RT_E_ARG;
-    rt_ctx *c = new rt_ctx();
+    rt_ctx *c = new (std::nothrow) rt_ctx();
+    if (!c) return RT_E_LIMIT;
     c->device = device_id;
-    auto bail = [&](hipError_t e) {
+    auto bail = [&](hipError_t e) { // every member is null-initialised and rt_destroy null-checks each one
         (void)e;
-        delete c;
+        (void)rt_destroy(c);
         return RT_E_HIP;
     };
     hipError_t e;
@@ -532,6 +543,7 @@ int rt_resize(rt_ctx *c, int nx, int ny, int ns) {
 }
 
 int rt_set_scene(rt_ctx *c, const rt_triangle148 *tris, int n) {
+    RT_TRY
     if (!c) return RT_E_ARG;
     if (!tris || n <= 0) return fail(c, RT_E_ARG, "empty scene");
     if (tris[0].shapeType != 0)
@@ -544,24 +556,36 @@ int rt_set_scene(rt_ctx *c, const rt_triangle148 *tris, int n) {
         if (tris[i].shapeType == 0 && (tris[i].texIdx < -1 || tris[i].texIdx >= RT_TEX_NUM))
             return fail(c, RT_E_ARG, "texIdx must be -1 (no texture) or an index below RT_TEX_NUM");
         if (tris[i].matType < 0 || tris[i].matType >= RT_MAT_NUM) return fail(c, RT_E_ARG, "matType out of range");
+        // non-finite coordinates would feed NaN keys to the builders' sort comparators (no strict weak order)
+        bool finite = true;
+        for (int k = 0; k < 3; k++) finite = finite && std::isfinite(tris[i].v0[k]);
+        if (tris[i].shapeType == 0)
+            for (int k = 0; k < 3; k++) finite = finite && std::isfinite(tris[i].v1[k]) && std::isfinite(tris[i].v2[k]);
+        else
+            finite = finite && std::isfinite(tris[i].v1[0]);
+        if (!finite) return fail(c, RT_E_ARG, "non-finite vertex or radius in primitive " + std::to_string(i));
     }
     HIPCHK(c, hipSetDevice(c->device));
     c->tris.assign(tris, tris + n);
     c->bnodes.clear();
     free_scene(c);
     return RT_OK;
+    RT_CATCH(c)
 }
 
 int rt_build_bvh(rt_ctx *c, int64_t rand_calls_before) {
+    RT_TRY
     if (!c) return RT_E_ARG;
     if (c->tris.empty()) return fail(c, RT_E_ARG, "no scene");
     if (rand_calls_before < 0) return fail(c, RT_E_ARG, "rand_calls_before < 0");
     HIPCHK(c, hipSetDevice(c->device));
     build_binary_bvh(c->tris.data(), (int)c->tris.size(), rand_calls_before, c->bnodes);
     return upload_scene(c);
+    RT_CATCH(c)
 }
 
 int rt_set_bvh_nodes(rt_ctx *c, const rt_bvh_node32 *nodes, int m) {
+    RT_TRY
     if (!c) return RT_E_ARG;
     if (c->tris.empty()) return fail(c, RT_E_ARG, "no scene");
     if (!nodes || m != 2 * (int)c->tris.size() - 1) return fail(c, RT_E_ARG, "node count must be 2*n-1");
@@ -570,9 +594,11 @@ int rt_set_bvh_nodes(rt_ctx *c, const rt_bvh_node32 *nodes, int m) {
     int rc = upload_scene(c);
     if (rc) c->bnodes.clear();
     return rc;
+    RT_CATCH(c)
 }
 
 int rt_get_bvh_nodes(rt_ctx *c, rt_bvh_node32 *out, int cap, int *m) {
+    RT_TRY
     if (!c || !m) return RT_E_ARG;
     *m = (int)c->bnodes.size();
     if (out) {
@@ -580,6 +606,7 @@ int rt_get_bvh_nodes(rt_ctx *c, rt_bvh_node32 *out, int cap, int *m) {
         std::memcpy(out, c->bnodes.data(), c->bnodes.size() * sizeof(rt_bvh_node32));
     }
     return RT_OK;
+    RT_CATCH(c)
 }
 
 int rt_set_materials(rt_ctx *c, const rt_material *mats, int n) {
@@ -781,6 +808,7 @@ static int render_into(rt_ctx *c, float *d_fb, rt_stats *st, double t0) {
 }
 
 int rt_render_device(rt_ctx *c, float *fb_rgb_device, rt_stats *st) {
+    RT_TRY
     if (!c || !fb_rgb_device) return RT_E_ARG;
     double t0 = now_ms();
     if (!c->cam_set) return fail(c, RT_E_ARG, "no camera: call rt_set_camera first");
@@ -788,9 +816,11 @@ int rt_render_device(rt_ctx *c, float *fb_rgb_device, rt_stats *st) {
     int rc = ready_to_trace(c);
     if (rc) return rc;
     return render_into(c, fb_rgb_device, st, t0);
+    RT_CATCH(c)
 }
 
 int rt_render(rt_ctx *c, float *fb_rgb_host, rt_stats *st) {
+    RT_TRY
     if (!c || !fb_rgb_host) return RT_E_ARG;
     double t0 = now_ms();
     if (!c->cam_set) return fail(c, RT_E_ARG, "no camera: call rt_set_camera first");
@@ -804,9 +834,11 @@ int rt_render(rt_ctx *c, float *fb_rgb_host, rt_stats *st) {
     HIPCHK(c, hipMemcpy(fb_rgb_host, c->d_fb, (size_t)c->nx * c->ny * 3 * sizeof(float), hipMemcpyDeviceToHost));
     if (st) st->total_ms = now_ms() - t0;
     return RT_OK;
+    RT_CATCH(c)
 }
 
 int rt_trace_primary(rt_ctx *c, int32_t *tri_id_host, float *t_host, rt_stats *st) {
+    RT_TRY
     if (!c || !tri_id_host || !t_host) return RT_E_ARG;
     double t0 = now_ms();
     if (!c->cam_set) return fail(c, RT_E_ARG, "no camera: call rt_set_camera first");
@@ -859,9 +891,11 @@ int rt_trace_primary(rt_ctx *c, int32_t *tri_id_host, float *t_host, rt_stats *s
     if (e != hipSuccess) return fail(c, RT_E_HIP, std::string("HIP error in rt_trace_primary: ") + hipGetErrorString(e));
     fill_stats(c, st, rays, ms, now_ms() - t0);
     return RT_OK;
+    RT_CATCH(c)
 }
 
 int rt_trace_rays(rt_ctx *c, const float *org_dir6, int n_rays, int32_t *tri_id_host, float *t_host, rt_stats *st) {
+    RT_TRY
     if (!c || !org_dir6 || !tri_id_host || !t_host || n_rays <= 0) return RT_E_ARG;
     double t0 = now_ms();
     HIPCHK(c, hipSetDevice(c->device));
@@ -908,6 +942,7 @@ int rt_trace_rays(rt_ctx *c, const float *org_dir6, int n_rays, int32_t *tri_id_
     if (e != hipSuccess) return fail(c, RT_E_HIP, std::string("HIP error in rt_trace_rays: ") + hipGetErrorString(e));
     fill_stats(c, st, rays, ms, now_ms() - t0);
     return RT_OK;
+    RT_CATCH(c)
 }
 
 int rt_write_ppm(const char *path, const float *fb, int nx, int ny) {
@@ -941,15 +976,18 @@ int rt_test_introsort(const float *key, int32_t *idx, int n) {
 }
 
 int rt_test_build_bvh(const rt_triangle148 *tris, int n, int64_t rand_calls_before, rt_bvh_node32 *out) {
+    RT_TRY
     if (!tris || !out || n <= 0 || rand_calls_before < 0) return RT_E_ARG;
     std::vector<rt_bvh_node32> nodes;
     build_binary_bvh(tris, n, rand_calls_before, nodes);
     std::memcpy(out, nodes.data(), nodes.size() * sizeof(rt_bvh_node32));
     return RT_OK;
+    RT_CATCH(nullptr)
 }
 
 int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size,
                         int box_mode, int topology, void *wide_nodes, void *quant_nodes, void *prims, int32_t info[4]) {
+    RT_TRY
     if (!tris || !nodes || !info) return RT_E_ARG;
     WideBvh w;
     std::string err;
@@ -963,6 +1001,7 @@ int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *
     if (quant_nodes) std::memcpy(quant_nodes, w.qnodes.data(), w.qnodes.size() * sizeof(QuantNode));
     if (prims) std::memcpy(prims, w.prims.data(), w.prims.size() * sizeof(DevPrim));
     return RT_OK;
+    RT_CATCH(nullptr)
 }
 
 int rt_test_trav_stats(rt_ctx *c, uint64_t out[40]) {
@@ -978,6 +1017,7 @@ int rt_test_trav_stats(rt_ctx *c, uint64_t out[40]) {
 
 int rt_trace_rays_device(rt_ctx *c, const float *org_dir6_device, int n_rays, int32_t *tri_id_device, float *t_device,
                          rt_stats *st) {
+    RT_TRY
     if (!c || !org_dir6_device || !tri_id_device || !t_device || n_rays <= 0) return RT_E_ARG;
     double t0 = now_ms();
     HIPCHK(c, hipSetDevice(c->device));
@@ -999,6 +1039,7 @@ int rt_trace_rays_device(rt_ctx *c, const float *org_dir6_device, int n_rays, in
     HIPCHK(c, hipMemcpy(&rays, c->d_counter, sizeof(rays), hipMemcpyDeviceToHost));
     fill_stats(c, st, rays, ms, now_ms() - t0);
     return RT_OK;
+    RT_CATCH(c)
 }
 
 int rt_test_dump_rays(rt_ctx *c, uint64_t capacity) {

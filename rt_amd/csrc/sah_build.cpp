@@ -145,11 +145,9 @@ struct Sah {
             });
         }
         const int64_t rbase = base + 2 * (int64_t)(mid - lo) - 1;
-        int32_t l, r;
+        int32_t l = 0, r = 0;
         if (depth < par_depth) {
-            std::thread left([&]() { l = build(lo, mid, depth + 1, base); });
-            r = build(mid, hi, depth + 1, rbase);
-            left.join();
+            fork_join([&]() { l = build(lo, mid, depth + 1, base); }, [&]() { r = build(mid, hi, depth + 1, rbase); });
         } else {
             l = build(lo, mid, depth + 1, base);
             r = build(mid, hi, depth + 1, rbase);

@@ -318,7 +318,9 @@ class PbrtEngine:
         return fb
 
     def renderDevice(self, device_ptr: int) -> RtStats:
-        """Same, into caller-owned device memory (e.g. a torch tensor's data_ptr())."""
+        """Same, into caller-owned device memory (e.g. a torch tensor's data_ptr()) of nx*ny*3 floats for the CURRENT
+        nx, ny: a setNx/setNy/setNs since the last render takes effect here, as in render()."""
+        self.uponPixelNumChange()
         self._check(self._lib.rt_render_device(self._h, C.c_void_p(device_ptr), C.byref(self.last_stats)),
                     "rt_render_device")
         return self.last_stats

@@ -490,13 +490,16 @@ def test_tiny_scenes_and_frames(oracle, n_extra, nx, ny, ns):
 
 def _textured_scene():
     """Light quad, a textured ground quad (coordinates beyond [0, 1]: wrap), a textured wall with another texture, an
-    untextured lambertian triangle, a metal triangle that names a texture (ignored: only lambertian reads it) and
-    spheres."""
+    untextured lambertian triangle, a metal triangle that names a texture (ignored: lambertian and diffusive_light
+    read it, material.h:100-106,140-146), a textured LIGHT quad (the reference's CAT scene has such walls,
+    main.cpp:596-641) and spheres."""
     v = np.array([[4, 10, -4], [-4, 10, -4], [-4, 10, 4], [4, 10, 4]], dtype=np.float32)
     g = np.array([[-8, 0, -8], [-8, 0, 8], [8, 0, 8], [8, 0, -8]], dtype=np.float32)
     w = np.array([[-6, 0, -5], [6, 0, -5], [6, 6, -5], [-6, 6, -5]], dtype=np.float32)
     guv = np.array([[-1.5, -1.5], [-1.5, 2.5], [2.5, 2.5], [2.5, -1.5]], dtype=np.float32)
     wuv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=np.float32)
+    lw = np.array([[7, 0, -4], [7, 0, 4], [7, 5, 4], [7, 5, -4]], dtype=np.float32)
+    luv = np.array([[0.1, 0.2], [1.7, 0.2], [1.7, 0.9], [0.1, 0.9]], dtype=np.float32)
     return np.concatenate([
         scenes.make_triangles(v[[3, 3]], v[[2, 1]], v[[1, 0]], 3),
         scenes.make_triangles(g[[0, 0]], g[[1, 2]], g[[2, 3]], 0, tex_idx=0, uv=np.stack([guv[[0, 1, 2]], guv[[0, 2, 3]]])),
@@ -505,13 +508,14 @@ def _textured_scene():
                               np.array([[3, 2, 3]], np.float32), 9),
         scenes.make_triangles(np.array([[-4, 0.01, 2]], np.float32), np.array([[-2, 0.01, 2]], np.float32),
                               np.array([[-3, 2.5, 1]], np.float32), 5, tex_idx=0, uv=np.array([[[0, 0], [1, 0], [0, 1]]])),
+        scenes.make_triangles(lw[[0, 0]], lw[[1, 2]], lw[[2, 3]], 3, tex_idx=0, uv=np.stack([luv[[0, 1, 2]], luv[[0, 2, 3]]])),
         scenes.make_spheres(np.array([[0, 1, 0], [2.5, 0.6, 3.5]], np.float32), [1.0, 0.6], 7),
     ])
 
 
 @pytest.mark.parametrize("kernel,fmt,topo", [(2, 1, 1), (1, 0, 0), (0, 0, 1), (3, 1, 1)])
 def test_textured_lambertian_bit_exact(oracle, kernel, fmt, topo):
-    """lambertian albedo from a texture (material.h:100-106) -- RGBA8 set through rt_set_texture,
+    """lambertian albedo and light emission from a texture (material.h:100-106, 140-146) -- RGBA8 set through rt_set_texture,
     sampled with the shared restatement of tex2D, hit (u, v) from the reference's barycentric blend.  Image bit-exact
     against the oracle for every kernel variant; a missing texture is an error, not a black surface."""
     rng = np.random.default_rng(11)
