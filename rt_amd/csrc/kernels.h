@@ -79,16 +79,15 @@ struct PersistLaunch {
     // "Rounds" at k_persistent
     int rounds;            // 1 = off; at most 63 and at most ns
     int round_end[64];     // round r runs the samples [round_end[r - 1], round_end[r]) of a pixel; round_end[rounds - 1] = ns
-    uint32_t *round_state; // kRingWords words per slot (n_local_tiles * 64 slots)
-    uint32_t *round_flag;  // one word per slot; zeroed once at allocation
-    uint32_t frame_id;     // never 0, below 2^26; flags of earlier launches compare unequal: no clearing per frame
+    uint32_t *round_state; // kRingWords words per slot (n_local_tiles * 64 slots), 16-byte aligned, zeroed once at allocation
+    uint32_t frame_id;     // never 0, below 2^26, never reused on a record array: tags of earlier launches compare unequal, no clearing per frame
     float *ray_dump = nullptr;                     // analysis builds: rt_test_dump_rays
     unsigned long long *ray_dump_count = nullptr;
     unsigned long long ray_dump_cap = 0;
     unsigned long long *wave_times = nullptr; // analysis builds: rt_test_wave_times
     unsigned long long *stats; // kTravStats counters, zeroed by the caller; only written by a -DRT_TRAV_STATS build
 };
-enum { kRingWords = 12 };
+enum { kRingWords = 20 }; // ten 8-byte {value, tag} granules per pixel slot
 // Lane-occupancy counters of the persistent kernel (analysis builds only, `make STATS=1`; tools/trav_stats.py)
 enum { kStatIters = 0, kStatNodeLanes, kStatStalledLanes, kStatIdleLanes, kStatLeafFires, kStatLeafLanes, kStatLeafPrims,
        kStatRefills, kStatShadeLanes, kStatPrimaryLanes, kStatFetchLanes, kStatNodeIters, kStatRetiredLanes, kStatWaitLanes, kStatSpinPolls, kStatPollFails /* 15: polls of a round flag that found the record missing */,

@@ -662,19 +662,53 @@ __device__ __forceinline__ void trav_begin(Trav &T, const Ray &r, uint32_t sp0) 
 // Accesses that must name global memory (a volatile or atomic access through a generic pointer becomes flat_*, which
 // waits on both counters and is not among the hand-off forms measured in MI355X_MICROARCH.md, "Valid forms").
 typedef __attribute__((address_space(1))) uint32_t gu32;
-// agent-scope relaxed atomics lower to global_load / global_store ... sc1: they bypass the per-CU L1 and the
-// non-coherent per-XCD L2 lines, which is what hands data from one CU to another inside a launch
-__device__ __forceinline__ uint32_t ld_sc1(const uint32_t *p) {
-    return __hip_atomic_load((const gu32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Round record of one pixel slot (see "Rounds" at k_persistent): ten 8-byte granules {value, tag} in five 16-byte
+// pieces, kRingWords words per slot.  Every piece is written by ONE buffer_store_dwordx4 ... sc1 (write-through: it
+// bypasses the writer's L1 and is dropped from its XCD's L2) and read by ONE buffer_load_dwordx4 ... sc1 (bypasses
+// the reader's L1): the data IS the flag.  This is recipe R2 of cdna_hip_programming.md, Guideline 16 -- naturally
+// aligned 8-byte granules that carry their own tag need no ordering between them, no drain on the writer and no
+// acquire on the reader (MI355X_MICROARCH.md, "Valid forms": observed untorn on gfx950 / ROCm 7.2, "also for 16-B sc1
+// halves"; measured there, not an architectural guarantee -- the assumption this hand-off rests on).  A reader
+// accepts a record only when all ten tags name the (frame, round) it waits for; a record that is half old and half
+// new fails that test and is polled again.  One writer and one reader per record and round, in turn.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ring_rsrc(uint32_t *state, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(state, 0, (int)bytes, 0x00020000);
 }
-__device__ __forceinline__ void st_sc1(uint32_t *p, uint32_t v) {
-    __hip_atomic_store((gu32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#define RT_AUX_SC1 16 /* cache-policy bits of the raw buffer builtins on gfx950: 16 = sc1 */
+// (The pixel state goes through scalars, not through a reference to the Rng struct: with the struct's address taken
+// here hipcc kept the whole RNG state in scratch memory for the rest of the kernel.)
+__device__ __forceinline__ void ring_publish(uint32_t *state, uint32_t bytes, uint32_t slot, uint32_t tag, uint32_t v0,
+                                             uint32_t v1, uint32_t v2, uint32_t v3, uint32_t v4, uint32_t d, V3 col, int k) {
+    const __amdgpu_buffer_rsrc_t rs = ring_rsrc(state, bytes);
+    const uint32_t off = slot * (uint32_t)(kRingWords * 4);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{v0, tag, v1, tag}, rs, off, 0, RT_AUX_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{v2, tag, v3, tag}, rs, off + 16u, 0, RT_AUX_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{v4, tag, d, tag}, rs, off + 32u, 0, RT_AUX_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(col.x), tag, __float_as_uint(col.y), tag}, rs, off + 48u, 0, RT_AUX_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(col.z), tag, (uint32_t)k, tag}, rs, off + 64u, 0, RT_AUX_SC1);
+}
+// one poll: five loads in flight together, one round trip; true when every granule carries `tag`, and then w[0..9] =
+// the ten values (RNG v0..v4, d; sum x, y, z; sample count)
+__device__ __forceinline__ bool ring_poll(uint32_t *state, uint32_t bytes, uint32_t slot, uint32_t tag, uint32_t (&w)[10]) {
+    const __amdgpu_buffer_rsrc_t rs = ring_rsrc(state, bytes);
+    const uint32_t off = slot * (uint32_t)(kRingWords * 4);
+    asm volatile("" ::: "memory"); // a poll is a fresh read every time: nothing of an earlier one may be reused
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, RT_AUX_SC1);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16u, 0, RT_AUX_SC1);
+    const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 32u, 0, RT_AUX_SC1);
+    const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 48u, 0, RT_AUX_SC1);
+    const u32x4 e = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 64u, 0, RT_AUX_SC1);
+    asm volatile("" ::: "memory");
+    w[0] = a.x, w[1] = a.z, w[2] = b.x, w[3] = b.z, w[4] = c.x, w[5] = c.z, w[6] = d.x, w[7] = d.z, w[8] = e.x, w[9] = e.z;
+    return ((a.y ^ tag) | (a.w ^ tag) | (b.y ^ tag) | (b.w ^ tag) | (c.y ^ tag) | (c.w ^ tag) | (d.y ^ tag) | (d.w ^ tag) |
+            (e.y ^ tag) | (e.w ^ tag)) == 0u;
 }
 
 // LDS through address-space-3 pointers and byte offsets: ds_read / ds_write with the offset in one register
 typedef __attribute__((address_space(3))) uint32_t lu32;
 typedef __attribute__((address_space(3))) char lchar;
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4 lu128;
 // child references of the node a lane is working on: [lane][slot], written with one ds_write_b128 and read back by
 // slot.  Picking one of four registers by a per-lane index costs seven vector instructions (two tests, three selects),
@@ -1071,8 +1105,8 @@ struct PersistArgs {
     int rounds;            // 1 = off
     int round_end[64];     // sample count at which round r hands the pixel on (the last one: ns)
     uint32_t chunk;        // slots a wave takes per atomic on its band counter (64 when rounds > 1)
-    uint32_t *round_state; // kRingWords words per slot
-    uint32_t *round_flag;  // one word per slot: frame_id * 64 + the round whose start state the slot holds
+    uint32_t *round_state; // kRingWords words per slot: ten {value, tag} granules, tag = frame_id * 64 + the round the record starts
+    uint32_t round_bytes;  // size of that array (the buffer descriptor's range)
     uint32_t frame_id;
 };
 
@@ -1082,15 +1116,15 @@ struct PersistArgs {
 // nothing left to do (tools/trav_stats.py).  The pixels started last set the length of that tail, so no pixel may
 // start late: the frame is walked in R rounds.  In round r a lane takes a slot exactly as before (same bands, same
 // chunks, same XCD affinity), runs samples [r*ns/R, (r+1)*ns/R) of that pixel, writes the pixel's state (RNG, sum,
-// sample count: 11 words) to the slot's record and goes on to the next slot; the lane that takes the slot in round
+// sample count: 10 words) to the slot's record and goes on to the next slot; the lane that takes the slot in round
 // r+1 -- any lane of any wave -- picks the state up.  All pixels advance together and the frame ends on units of
 // ns/R samples.  A record has one writer and one reader per round, in turn, so one record per slot is enough; its
-// flag names the round it holds (frame_id * 64 + round).  A lane whose record is not there yet keeps the slot and
+// tags name the round it holds (frame_id * 64 + round).  A lane whose record is not there yet keeps the slot and
 // polls; the writer never waits for anything, so this cannot deadlock.  Who runs which samples cannot change a value.
-// Hand-off between lanes of different CUs / XCDs (MI355X_MICROARCH.md, "Valid forms"): every word of the record and
-// the flag are written by global_store ... sc1 and read by global_load ... sc1 (ld_sc1 / st_sc1), the writing wave
-// drains its stores (s_waitcnt vmcnt(0)) before the flag store, and the reader loads the record only after its own
-// poll of the flag has matched.
+// Hand-off between lanes of different CUs / XCDs: self-tagged 8-byte granules, written and read sc1 (RingRec above).
+// The writer does not wait for its stores and the reader needs one round trip, where a separate flag word needed a
+// drain (s_waitcnt vmcnt(0), which also waits for every load the wave has in flight) before the flag store and a
+// second, dependent round trip after the poll.
 
 #ifdef RT_TRAV_STATS
 #define RT_STAT(I, V) st[I] += (unsigned long long)(V)
@@ -1198,23 +1232,9 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
         const unsigned long long clk_shade = __builtin_readcyclecounter();
         RT_STAT(kStatShadeClocks, clk_shade - clk0);
 #endif
-        if (ring_on && want_push) { // end of this round's share: publish state, drain, flag
-            const uint32_t my_slot = slot_round & 0x3FFFFFFu;
-            uint32_t *sp = P.round_state + (size_t)my_slot * kRingWords;
-            st_sc1(sp + 1, g.v0);
-            st_sc1(sp + 2, g.v1);
-            st_sc1(sp + 3, g.v2);
-            st_sc1(sp + 4, g.v3);
-            st_sc1(sp + 5, g.v4);
-            st_sc1(sp + 6, g.d);
-            st_sc1(sp + 7, __float_as_uint(col.x));
-            st_sc1(sp + 8, __float_as_uint(col.y));
-            st_sc1(sp + 9, __float_as_uint(col.z));
-            st_sc1(sp + 10, (uint32_t)k);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every store of the record has left before the flag goes
-            // (merging this drain with the wait of the polls further down -- one round trip instead of two -- was measured:
-            // 39.3 vs 38.4 ms; the flag reaches its reader later and every refill pays the drain)
-            st_sc1(P.round_flag + my_slot, P.frame_id * 64u + (slot_round >> 26) + 1u); // next round's tag
+        if (ring_on && want_push) { // end of this round's share: publish the state under the next round's tag
+            ring_publish(P.round_state, P.round_bytes, slot_round & 0x3FFFFFFu, P.frame_id * 64u + (slot_round >> 26) + 1u, g.v0, g.v1,
+                         g.v2, g.v3, g.v4, g.d, col, k);
             has_pixel = false;
         }
 #ifdef RT_TRAV_STATS
@@ -1257,17 +1277,11 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                 }
             }
             if (ring_on && waiting) { // has the previous round's lane published it yet?
-                const uint32_t my_slot = slot_round & 0x3FFFFFFu;
-                if (ld_sc1(P.round_flag + my_slot) == P.frame_id * 64u + (slot_round >> 26)) {
-                    const uint32_t *sp = P.round_state + (size_t)my_slot * kRingWords; // loaded only after the poll matched
-                    g.v0 = ld_sc1(sp + 1);
-                    g.v1 = ld_sc1(sp + 2);
-                    g.v2 = ld_sc1(sp + 3);
-                    g.v3 = ld_sc1(sp + 4);
-                    g.v4 = ld_sc1(sp + 5);
-                    g.d = ld_sc1(sp + 6);
-                    col = mk(__uint_as_float(ld_sc1(sp + 7)), __uint_as_float(ld_sc1(sp + 8)), __uint_as_float(ld_sc1(sp + 9)));
-                    k = (int)ld_sc1(sp + 10);
+                uint32_t w[10];
+                if (ring_poll(P.round_state, P.round_bytes, slot_round & 0x3FFFFFFu, P.frame_id * 64u + (slot_round >> 26), w)) {
+                    g.v0 = w[0], g.v1 = w[1], g.v2 = w[2], g.v3 = w[3], g.v4 = w[4], g.d = w[5];
+                    col = mk(__uint_as_float(w[6]), __uint_as_float(w[7]), __uint_as_float(w[8]));
+                    k = (int)w[9];
                     has_pixel = true;
                     need_primary = true;
                     waiting = false;
@@ -1835,10 +1849,11 @@ hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &
     // 1080p frame) set the kernel's time -- 0.65 ms, 0.53 with 256 slots per atomic
     P.chunk = mode == 1 && L.primary_chunk >= 64 ? (uint32_t)L.primary_chunk : 64u;
     P.round_state = L.round_state;
-    P.round_flag = L.round_flag;
     P.frame_id = L.frame_id;
-    if (P.rounds > 1 && (!P.round_state || !P.round_flag || P.frame_id == 0u || P.rounds > 63 || P.rounds > F.ns ||
-                         (uint64_t)F.n_local_tiles * 64u >= (1ull << 26)))
+    const uint64_t ring_bytes = (uint64_t)F.n_local_tiles * 64u * kRingWords * 4u;
+    P.round_bytes = (uint32_t)ring_bytes;
+    if (P.rounds > 1 && (!P.round_state || P.frame_id == 0u || P.frame_id >= (1u << 26) || P.rounds > 63 || P.rounds > F.ns ||
+                         (uint64_t)F.n_local_tiles * 64u >= (1ull << 26) || ring_bytes > 0xFFFFFFFFull))
         return hipErrorInvalidValue;
     const dim3 grid(L.grid_waves), block(64);
     if (mode == 0 && L.dual) {

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -33,9 +34,9 @@ struct rt_ctx {
     int nx = 640, ny = 360, ns = 10, max_depth = 50;
     int honor_vfov = 0, leaf_size = 2, box_mode = 0, shard_rank = 0, shard_world = 1, kernel_variant = 2;
     int shade_batch = 32, swap_batch = 8, tail_split = 0, tail_taper = 150; // tail_split 0: by frame size
-    uint32_t *d_ring_state = nullptr, *d_ring_flag = nullptr;
+    uint32_t *d_ring_state = nullptr; // round records, kRingWords words per pixel slot
     size_t ring_items = 0;
-    uint32_t frame_id = 0;
+    uint64_t ring_generation = 0;     // frame-id generation (next_frame_tag) the records were last zeroed in
     unsigned long long seed_salt = 0;
     int raw_sum = 0;
     int queue_threshold = 48; // k_trace_queue: hand out rays when fewer lanes than this still traverse
@@ -208,12 +209,9 @@ int upload_scene(rt_ctx *c) {
     return RT_OK;
 }
 
-// every texture a triangle names must have been set; the descriptor table is refreshed when a texture changed
+// the descriptor table follows every rt_set_texture at once (d_tex is allocated at rt_create), so that a render has
+// nothing left to upload
 int upload_textures(rt_ctx *c) {
-    if (c->wide.uv.empty()) return RT_OK;
-    for (const DevUV &q : c->wide.uv)
-        if (q.tex != -1 && !c->d_texels[q.tex])
-            return fail(c, RT_E_ARG, "a triangle names texture " + std::to_string(q.tex) + ", which was never set (rt_set_texture)");
     if (!c->tex_dirty) return RT_OK;
     DevTex tmp[RT_TEX_NUM];
     for (int i = 0; i < RT_TEX_NUM; i++) {
@@ -221,10 +219,16 @@ int upload_textures(rt_ctx *c) {
         tmp[i].w = c->tex_w[i];
         tmp[i].h = c->tex_h[i];
     }
-    if (!c->d_tex) HIPCHK(c, hipMalloc((void **)&c->d_tex, sizeof(tmp)));
     HIPCHK(c, hipMemcpyAsync(c->d_tex, tmp, sizeof(tmp), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->tex_dirty = false;
+    return RT_OK;
+}
+// every texture a triangle names must have been set (host-side check, touches no device memory)
+int check_textures(rt_ctx *c) {
+    for (const DevUV &q : c->wide.uv)
+        if (q.tex != -1 && !c->d_texels[q.tex])
+            return fail(c, RT_E_ARG, "a triangle names texture " + std::to_string(q.tex) + ", which was never set (rt_set_texture)");
     return RT_OK;
 }
 
@@ -260,7 +264,9 @@ int ready_to_trace(rt_ctx *c) {
         int rc = upload_scene(c);
         if (rc) return rc;
     }
-    int rc = upload_textures(c);
+    int rc = check_textures(c);
+    if (rc) return rc;
+    rc = upload_textures(c);
     if (rc) return rc;
     return upload_mats(c);
 }
@@ -307,6 +313,21 @@ void fill_stats(rt_ctx *c, rt_stats *st, uint64_t rays, float ms, double total_m
     st->reserved = 0;
 }
 
+// The tag of a round record is frame_id * 64 + round, and a record array is never cleared between frames: that needs
+// frame ids that no array sees twice.  They are drawn per DEVICE, not per context, so that arrays shared by the
+// contexts of a device can rely on them too: ids run 1 .. 2^26 - 1 and then start over in a new "generation"; an
+// array that was last zeroed in another generation is zeroed again before it is used.
+constexpr int kMaxDevices = 64;
+constexpr uint64_t kFrameIds = (1ull << 26) - 1;
+std::mutex g_frame_mutex;
+uint64_t g_frames_issued[kMaxDevices] = {};
+void next_frame_tag(int device, uint32_t &id, uint64_t &generation) {
+    std::lock_guard<std::mutex> lock(g_frame_mutex);
+    const uint64_t n = g_frames_issued[device]++;
+    id = (uint32_t)(n % kFrameIds) + 1u;
+    generation = n / kFrameIds + 1u; // never 0: a fresh array (generation 0) is always zeroed first
+}
+
 // kernel variant 1: zero the band counters, size the spill area, fill the launch record
 enum LaunchKind { kLaunchRender, kLaunchPrimary, kLaunchRays };
 int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_rays = 0) {
@@ -350,7 +371,7 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_ra
     L.spill = c->d_spill;
     L.band_counters = c->d_bands;
     L.rounds = 1;
-    L.round_state = L.round_flag = nullptr;
+    L.round_state = nullptr;
     L.frame_id = 0;
     const long tiles = (long)((c->nx + 7) / 8) * ((c->ny + 7) / 8);
     const size_t slots = (size_t)((tiles - c->shard_rank + c->shard_world - 1) / c->shard_world) * 64;
@@ -364,22 +385,24 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_ra
         want_rounds = std::max(2, std::min(want_rounds, 8));
     }
     const int rounds = std::min(std::min(want_rounds, c->ns), 63);
-    if (render && rounds > 1 && c->kernel_variant != 3 && slots > 0 && slots < ((size_t)1 << 26)) { // slot | round << 26
+    // slot | round << 26 in one register; the record array is addressed through a buffer descriptor (32-bit byte offsets)
+    if (render && rounds > 1 && c->kernel_variant != 3 && slots > 0 && slots < ((size_t)1 << 26) &&
+        slots * kRingWords * sizeof(uint32_t) <= 0xFFFFFFFFull) {
         if (slots > c->ring_items) {
             if (c->d_ring_state) (void)hipFree(c->d_ring_state);
-            if (c->d_ring_flag) (void)hipFree(c->d_ring_flag);
-            c->d_ring_state = c->d_ring_flag = nullptr;
+            c->d_ring_state = nullptr;
             c->ring_items = 0;
             HIPCHK(c, hipMalloc((void **)&c->d_ring_state, slots * kRingWords * sizeof(uint32_t)));
-            HIPCHK(c, hipMalloc((void **)&c->d_ring_flag, slots * sizeof(uint32_t)));
-            HIPCHK(c, hipMemsetAsync(c->d_ring_flag, 0, slots * sizeof(uint32_t), c->stream));
             c->ring_items = slots;
-            c->frame_id = 0;
+            c->ring_generation = 0;
         }
-        if (++c->frame_id >= (1u << 26)) { // the tag is frame_id * 64 + round: start over before it wraps
-            HIPCHK(c, hipMemsetAsync(c->d_ring_flag, 0, c->ring_items * sizeof(uint32_t), c->stream));
-            c->frame_id = 1;
+        uint64_t generation;
+        next_frame_tag(c->device, L.frame_id, generation);
+        if (generation != c->ring_generation) { // fresh array, or the ids have started over since it was last zeroed
+            HIPCHK(c, hipMemsetAsync(c->d_ring_state, 0, c->ring_items * kRingWords * sizeof(uint32_t), c->stream));
+            c->ring_generation = generation;
         }
+        L.round_state = c->d_ring_state;
         L.rounds = rounds;
         // Shares of the rounds: boundary r at ns * (1 - (1 - r/R)^p), p = RT_OPT_TAIL_TAPER / 100.  p = 1: equal
         // shares; p > 1: the last rounds are short, and what is still running when the work has been handed out is
@@ -394,11 +417,8 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_ra
                 L.round_end[r] = prev = k;
             }
         }
-        L.round_state = c->d_ring_state;
-        L.round_flag = c->d_ring_flag;
-        L.frame_id = c->frame_id;
     }
-    L.stats = reinterpret_cast<unsigned long long *>(c->d_bands + 16);
+    L.stats = reinterpret_cast<unsigned long long *>(L.band_counters + 16);
     if (kind != kLaunchRays && c->d_wave_times && (size_t)L.grid_waves <= c->wave_times_cap) L.wave_times = c->d_wave_times;
     if (render && c->d_ray_dump) {
         L.ray_dump = c->d_ray_dump;
@@ -406,7 +426,7 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_ra
         L.ray_dump_cap = c->ray_dump_cap;
         HIPCHK(c, hipMemsetAsync(c->d_ray_dump_count, 0, sizeof(unsigned long long), c->stream));
     }
-    HIPCHK(c, hipMemsetAsync(c->d_bands, 0, kBandBytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(L.band_counters, 0, kBandBytes, c->stream));
     return RT_OK;
 }
 
@@ -433,7 +453,7 @@ int rt_set_texture(rt_ctx *c, int index, const uint8_t *rgba8, int w, int h) {
     c->tex_w[index] = w;
     c->tex_h[index] = h;
     c->tex_dirty = true;
-    return RT_OK;
+    return upload_textures(c);
 }
 
 int rt_default_materials(rt_material out[RT_MAT_NUM]) {
@@ -477,7 +497,7 @@ int rt_create(rt_ctx **out, int device_id) {
     *out = nullptr;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return RT_E_HIP; // no CPU fallback
-    if (device_id < 0 || device_id >= count) return RT_E_ARG;
+    if (device_id < 0 || device_id >= count || device_id >= kMaxDevices) return RT_E_ARG;
     rt_ctx *c = new (std::nothrow) rt_ctx();
     if (!c) return RT_E_LIMIT;
     c->device = device_id;
@@ -499,7 +519,9 @@ int rt_create(rt_ctx **out, int device_id) {
         if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail(e);
         c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    if ((e = hipMalloc((void **)&c->d_tex, sizeof(DevTex) * RT_TEX_NUM)) != hipSuccess) return bail(e);
     rt_default_materials(c->mats);
+    if (upload_mats(c) != RT_OK || upload_textures(c) != RT_OK) return bail(hipErrorUnknown);
     *out = c;
     return RT_OK;
 }
@@ -519,7 +541,6 @@ int rt_destroy(rt_ctx *c) {
     for (int i = 0; i < RT_TEX_NUM; i++)
         if (c->d_texels[i]) (void)hipFree(c->d_texels[i]);
     if (c->d_ring_state) (void)hipFree(c->d_ring_state);
-    if (c->d_ring_flag) (void)hipFree(c->d_ring_flag);
     if (c->d_spill) (void)hipFree(c->d_spill);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -616,7 +637,8 @@ int rt_set_materials(rt_ctx *c, const rt_material *mats, int n) {
         if (mats[i].kind < RT_MAT_LAMBERTIAN || mats[i].kind > RT_MAT_LIGHT) return fail(c, RT_E_ARG, "bad material kind");
     std::memcpy(c->mats, mats, sizeof(rt_material) * (size_t)n);
     c->mats_dirty = true;
-    return RT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    return upload_mats(c); // at once: a render finds the table resident
 }
 
 int rt_set_camera(rt_ctx *c, const float lookfrom[3], const float lookat[3], float vfov, float dist_to_focus,
@@ -784,7 +806,7 @@ int rt_get_option(rt_ctx *c, int option, int64_t *value) {
 static int render_into(rt_ctx *c, float *d_fb, rt_stats *st, double t0) {
     KernelFrame F;
     fill_frame(c, F);
-    HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(F.ray_counter, 0, sizeof(unsigned long long), c->stream));
     if (c->shard_world > 1) // pixels of other ranks' tiles read as 0, so that a sum over ranks assembles the frame
         HIPCHK(c, hipMemsetAsync(d_fb, 0, (size_t)c->nx * c->ny * 3 * sizeof(float), c->stream));
     PersistLaunch L;
@@ -802,7 +824,7 @@ static int render_into(rt_ctx *c, float *d_fb, rt_stats *st, double t0) {
     float ms = 0.0f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     unsigned long long rays = 0;
-    HIPCHK(c, hipMemcpy(&rays, c->d_counter, sizeof(rays), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&rays, F.ray_counter, sizeof(rays), hipMemcpyDeviceToHost));
     fill_stats(c, st, rays, ms, now_ms() - t0);
     return RT_OK;
 }
