@@ -171,6 +171,20 @@ int rt_render(rt_ctx *ctx, float *fb_rgb_host, rt_stats *stats);
  * device); the call returns after the kernel has completed. */
 int rt_render_device(rt_ctx *ctx, float *fb_rgb_device, rt_stats *stats);
 
+/* rt_render_device for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same frame (bit for bit), same
+ * kernels as rt_render_device, but every scratch buffer of the launch -- band counters, ray counter, the traversal
+ * stacks' spill area, the round records -- comes out of ONE static device array of 64 MiB that the library holds on
+ * every GPU it runs on until the process ends, and the call itself makes no hipMalloc / hipFree and uploads nothing:
+ * scene, BVH, materials and textures must be resident (rt_build_bvh / rt_set_bvh_nodes, rt_set_materials and
+ * rt_set_texture upload when they are called; after a layout option changed, build again or call rt_render_device
+ * once).  Limits, refused with RT_E_LIMIT and a message: frames of more than 314 572 pixel slots (8x8 tiles x 64;
+ * the reference's default 640x360 fits, 1280x720 does not) when the frame is rendered in rounds (RT_OPT_TAIL_SPLIT
+ * != 1; with 1 any frame size runs), and scenes whose traversal stacks spill more than 40 MiB - 4 KiB (stack entries
+ * beyond RT_OPT_LDS_STACK x RT_OPT_WAVES_PER_CU x CUs x 256 bytes; the 1 M-triangle bench scene spills 37.7 MB).  All contexts of one GPU share that GPU's array: calls of
+ * this entry point that overlap in time on one GPU race; calls in sequence need no clearing by the caller. */
+int rt_render_device_noalloc(rt_ctx *ctx, float *fb_rgb_device, rt_stats *stats);
+
 /* Parity hook (no reference counterpart): the primary ray of sample 0 of every pixel
  * (pbrt_engine.cu:584-586), closest hit via hit() (:371).  tri_id = index into the rt_set_scene
  * array, -1 on a miss; t = rec.t (0 on a miss).  Host buffers of nx*ny. */

@@ -93,6 +93,24 @@ enum { kStatIters = 0, kStatNodeLanes, kStatStalledLanes, kStatIdleLanes, kStatL
        kStatRefills, kStatShadeLanes, kStatPrimaryLanes, kStatFetchLanes, kStatNodeIters, kStatRetiredLanes, kStatWaitLanes, kStatSpinPolls, kStatPollFails /* 15: polls of a round flag that found the record missing */,
        kStatNodeLanesByBounce = 16 /* .. 23: bounce 0..6, 7+ */, kStatItersWithBounce = 24 /* .. 31 */,
        kStatRefillClocks = 32, kStatTravClocks, kStatShadeClocks, kStatNodeClocks, kStatLeafClocks, kStatPublishClocks, kStatFetchClocks, kStatPrimaryClocks, kTravStats = 40 };
+// Device memory for callers that cannot allocate (rt_render_device_noalloc): ONE file-scope __device__ array in
+// kernels.hip, kStaticScratchBytes per GPU, held from the code object's load on that GPU to the end of the process.
+// static_scratch() returns its address on `device`, which must be the current device: the first call per device looks
+// the symbol up (hipGetSymbolAddress) and zeroes the array; later calls return the kept pointer.  Layout (offsets):
+//   kStaticBandsOff    band counters + analysis counters (kStaticBandsBytes)
+//   kStaticCounterOff  ray counter (8 bytes)
+//   kStaticSpillOff    traversal-stack spill area (kStaticSpillBytes)
+//   kStaticRingOff     round records (kStaticRingBytes)
+constexpr size_t kStaticScratchBytes = (size_t)64 << 20;
+constexpr size_t kStaticBandsOff = 0, kStaticBandsBytes = 512;
+constexpr size_t kStaticCounterOff = 512;
+// (the bench scene -- 1 M triangles, 41 stack entries of which 16 live in LDS, 24 waves per CU -- spills 37.7 MB; the
+// reference's default frame, 640x360, needs 18.4 MB of records)
+constexpr size_t kStaticSpillOff = 4096, kStaticSpillBytes = ((size_t)40 << 20) - 4096;
+constexpr size_t kStaticRingOff = (size_t)40 << 20, kStaticRingBytes = (size_t)24 << 20;
+static_assert(kStaticRingOff + kStaticRingBytes == kStaticScratchBytes && kStaticRingOff % 256 == 0, "static scratch layout");
+hipError_t static_scratch(int device, void **ptr);
+
 hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &F, const PersistLaunch &L, float *fb,
                              int32_t *ids, float *ts, hipStream_t stream);
 hipError_t launch_render(const KernelScene &S, const KernelFrame &F, int stack_entries, float *fb, hipStream_t stream);

@@ -20,6 +20,7 @@
 
 #include <cfloat>
 #include <cstdint>
+#include <mutex>
 
 #include "kernels.h"
 #include "rt_shared_math.h"
@@ -1761,6 +1762,30 @@ __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, 
         for (int i = 0; i < kTravStats; i++)
             if (st[i]) atomicAdd(&P.stats[i], st[i]);
 #endif
+}
+
+// ------------------------------------------------------------------ static scratch (kernels.h, static_scratch)
+// In host code the array's name is only a stand-in for the symbol: it is never passed to a kernel or to a HIP call as
+// an address.  The address on a device comes from hipGetSymbolAddress, once per device (every GPU holds its own copy of
+// the array at its own address), and only that pointer is used afterwards.
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+hipError_t static_scratch(int device, void **ptr) {
+    constexpr int kMaxDev = 64;
+    static std::mutex mu;
+    static void *kept[kMaxDev] = {};
+    if (!ptr || device < 0 || device >= kMaxDev) return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!kept[device]) {
+        void *p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        if ((e = hipMemset(p, 0, kStaticScratchBytes)) != hipSuccess) return e; // counters and record tags start at zero
+        kept[device] = p;
+    }
+    *ptr = kept[device];
+    return hipSuccess;
 }
 
 // ------------------------------------------------------------------ launchers (host)

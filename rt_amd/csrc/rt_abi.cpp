@@ -58,6 +58,7 @@ struct rt_ctx {
     bool tex_dirty = true;
     int refill_threshold = 24, waves_per_cu = 24, lds_stack = 16, node_format = 1, leaf_batch = 16, occupancy = 6, topology = 1;
     int n_cus = 256;
+    unsigned char *static_area = nullptr; // this device's static scratch (kernels.h), looked up at rt_create
     unsigned int *d_bands = nullptr;
     uint32_t *d_spill = nullptr;
     size_t spill_words = 0;
@@ -329,8 +330,12 @@ void next_frame_tag(int device, uint32_t &id, uint64_t &generation) {
 }
 
 // kernel variant 1: zero the band counters, size the spill area, fill the launch record
+uint64_t g_static_ring_generation[kMaxDevices] = {}; // as rt_ctx::ring_generation, for a device's static record area
+
 enum LaunchKind { kLaunchRender, kLaunchPrimary, kLaunchRays };
-int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_rays = 0) {
+// no_alloc: every scratch buffer comes out of the device's static area (kernels.h) instead of the context's own
+// allocations; what does not fit is refused (RT_E_LIMIT), nothing is allocated or freed.
+int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_rays = 0, bool no_alloc = false) {
     const bool render = kind == kLaunchRender;
     // Render: waves_per_cu.  Textured scenes run the 128-VGPR instances (4 waves/SIMD): no point in launching more
     // waves than are resident.  Primary rays are short and coherent, and every wave launched costs a ramp of atomics
@@ -361,15 +366,19 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_ra
     L.occupancy = c->occupancy;
     int spill_entries = c->wide.stack_entries - L.lds_entries;
     size_t words = (size_t)(spill_entries > 0 ? spill_entries : 1) * (size_t)L.grid_waves * 64;
-    if (words > c->spill_words) {
+    if (no_alloc) {
+        if (words * sizeof(uint32_t) > kStaticSpillBytes)
+            return fail(c, RT_E_LIMIT, "the scene's tree is too deep for the static scratch: its traversal stacks spill " +
+                                           std::to_string(words * sizeof(uint32_t)) + " bytes, the limit is " + std::to_string(kStaticSpillBytes));
+    } else if (words > c->spill_words) {
         if (c->d_spill) (void)hipFree(c->d_spill);
         c->d_spill = nullptr;
         c->spill_words = 0;
         HIPCHK(c, hipMalloc((void **)&c->d_spill, words * sizeof(uint32_t)));
         c->spill_words = words;
     }
-    L.spill = c->d_spill;
-    L.band_counters = c->d_bands;
+    L.spill = no_alloc ? reinterpret_cast<uint32_t *>(c->static_area + kStaticSpillOff) : c->d_spill;
+    L.band_counters = no_alloc ? reinterpret_cast<unsigned int *>(c->static_area + kStaticBandsOff) : c->d_bands;
     L.rounds = 1;
     L.round_state = nullptr;
     L.frame_id = 0;
@@ -388,21 +397,36 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_ra
     // slot | round << 26 in one register; the record array is addressed through a buffer descriptor (32-bit byte offsets)
     if (render && rounds > 1 && c->kernel_variant != 3 && slots > 0 && slots < ((size_t)1 << 26) &&
         slots * kRingWords * sizeof(uint32_t) <= 0xFFFFFFFFull) {
-        if (slots > c->ring_items) {
-            if (c->d_ring_state) (void)hipFree(c->d_ring_state);
-            c->d_ring_state = nullptr;
-            c->ring_items = 0;
-            HIPCHK(c, hipMalloc((void **)&c->d_ring_state, slots * kRingWords * sizeof(uint32_t)));
-            c->ring_items = slots;
-            c->ring_generation = 0;
+        uint32_t *records;
+        size_t record_bytes;
+        uint64_t *zeroed_in;
+        if (no_alloc) {
+            if (slots * kRingWords * sizeof(uint32_t) > kStaticRingBytes)
+                return fail(c, RT_E_LIMIT, "frame too large for the static scratch: " + std::to_string(slots) + " pixel slots, the limit is " +
+                                               std::to_string(kStaticRingBytes / (kRingWords * sizeof(uint32_t))));
+            records = reinterpret_cast<uint32_t *>(c->static_area + kStaticRingOff);
+            record_bytes = kStaticRingBytes;
+            zeroed_in = &g_static_ring_generation[c->device];
+        } else {
+            if (slots > c->ring_items) {
+                if (c->d_ring_state) (void)hipFree(c->d_ring_state);
+                c->d_ring_state = nullptr;
+                c->ring_items = 0;
+                HIPCHK(c, hipMalloc((void **)&c->d_ring_state, slots * kRingWords * sizeof(uint32_t)));
+                c->ring_items = slots;
+                c->ring_generation = 0;
+            }
+            records = c->d_ring_state;
+            record_bytes = c->ring_items * kRingWords * sizeof(uint32_t);
+            zeroed_in = &c->ring_generation;
         }
         uint64_t generation;
         next_frame_tag(c->device, L.frame_id, generation);
-        if (generation != c->ring_generation) { // fresh array, or the ids have started over since it was last zeroed
-            HIPCHK(c, hipMemsetAsync(c->d_ring_state, 0, c->ring_items * kRingWords * sizeof(uint32_t), c->stream));
-            c->ring_generation = generation;
+        if (generation != *zeroed_in) { // fresh array, or the ids have started over since it was last zeroed
+            HIPCHK(c, hipMemsetAsync(records, 0, record_bytes, c->stream));
+            *zeroed_in = generation;
         }
-        L.round_state = c->d_ring_state;
+        L.round_state = records;
         L.rounds = rounds;
         // Shares of the rounds: boundary r at ns * (1 - (1 - r/R)^p), p = RT_OPT_TAIL_TAPER / 100.  p = 1: equal
         // shares; p > 1: the last rounds are short, and what is still running when the work has been handed out is
@@ -419,8 +443,8 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_ra
         }
     }
     L.stats = reinterpret_cast<unsigned long long *>(L.band_counters + 16);
-    if (kind != kLaunchRays && c->d_wave_times && (size_t)L.grid_waves <= c->wave_times_cap) L.wave_times = c->d_wave_times;
-    if (render && c->d_ray_dump) {
+    if (!no_alloc && kind != kLaunchRays && c->d_wave_times && (size_t)L.grid_waves <= c->wave_times_cap) L.wave_times = c->d_wave_times;
+    if (!no_alloc && render && c->d_ray_dump) {
         L.ray_dump = c->d_ray_dump;
         L.ray_dump_count = c->d_ray_dump_count;
         L.ray_dump_cap = c->ray_dump_cap;
@@ -520,6 +544,13 @@ int rt_create(rt_ctx **out, int device_id) {
         c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     if ((e = hipMalloc((void **)&c->d_tex, sizeof(DevTex) * RT_TEX_NUM)) != hipSuccess) return bail(e);
+    {
+        // the library's set-up call: this device's copy of the static scratch array is looked up (and zeroed) here, once
+        // per device, with the device current; entry points only ever see the pointer kept from this call
+        void *p = nullptr;
+        if ((e = static_scratch(device_id, &p)) != hipSuccess) return bail(e);
+        c->static_area = static_cast<unsigned char *>(p);
+    }
     rt_default_materials(c->mats);
     if (upload_mats(c) != RT_OK || upload_textures(c) != RT_OK) return bail(hipErrorUnknown);
     *out = c;
@@ -803,15 +834,16 @@ int rt_get_option(rt_ctx *c, int option, int64_t *value) {
     }
 }
 
-static int render_into(rt_ctx *c, float *d_fb, rt_stats *st, double t0) {
+static int render_into(rt_ctx *c, float *d_fb, rt_stats *st, double t0, bool no_alloc = false) {
     KernelFrame F;
     fill_frame(c, F);
+    if (no_alloc) F.ray_counter = reinterpret_cast<unsigned long long *>(c->static_area + kStaticCounterOff);
     HIPCHK(c, hipMemsetAsync(F.ray_counter, 0, sizeof(unsigned long long), c->stream));
     if (c->shard_world > 1) // pixels of other ranks' tiles read as 0, so that a sum over ranks assembles the frame
         HIPCHK(c, hipMemsetAsync(d_fb, 0, (size_t)c->nx * c->ny * 3 * sizeof(float), c->stream));
     PersistLaunch L;
     if (c->kernel_variant >= 1) {
-        int rc = prepare_persistent(c, L, kLaunchRender);
+        int rc = prepare_persistent(c, L, kLaunchRender, 0, no_alloc);
         if (rc) return rc;
     }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -827,6 +859,24 @@ static int render_into(rt_ctx *c, float *d_fb, rt_stats *st, double t0) {
     HIPCHK(c, hipMemcpy(&rays, F.ray_counter, sizeof(rays), hipMemcpyDeviceToHost));
     fill_stats(c, st, rays, ms, now_ms() - t0);
     return RT_OK;
+}
+
+int rt_render_device_noalloc(rt_ctx *c, float *fb_rgb_device, rt_stats *st) {
+    if (!c || !fb_rgb_device) return RT_E_ARG;
+    RT_TRY
+    double t0 = now_ms();
+    if (!c->cam_set) return fail(c, RT_E_ARG, "no camera: call rt_set_camera first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->tris.empty() || c->bnodes.empty()) return fail(c, RT_E_ARG, "no scene / no BVH: call rt_set_scene and rt_build_bvh first");
+    // everything a render reads must be resident already: this call uploads and allocates nothing
+    if (!c->scene_on_device)
+        return fail(c, RT_E_ARG, "the device scene is not resident (a layout option changed since the build): call rt_build_bvh, "
+                                 "rt_set_bvh_nodes or rt_render_device first");
+    if (c->mats_dirty || c->tex_dirty) return fail(c, RT_E_ARG, "material or texture tables are not resident");
+    int rc = check_textures(c);
+    if (rc) return rc;
+    return render_into(c, fb_rgb_device, st, t0, true);
+    RT_CATCH(c)
 }
 
 int rt_render_device(rt_ctx *c, float *fb_rgb_device, rt_stats *st) {

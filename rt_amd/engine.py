@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "rt_set_option", "rt_get_option", "rt_render", "rt_render_device", "rt_trace_primary", "rt_trace_rays",
     "rt_write_ppm", "rt_test_glibc_rand", "rt_test_introsort", "rt_test_build_bvh", "rt_test_wide_layout", "rt_test_tile_owner", "rt_test_fastdiv",
     "rt_test_trav_stats", "rt_test_sincosf", "rt_set_texture", "rt_trace_rays_device", "rt_test_dump_rays", "rt_test_wave_times",
-    "rt_test_trace_dumped",
+    "rt_test_trace_dumped", "rt_render_device_noalloc",
 ]
 
 
@@ -107,6 +107,7 @@ def load_library(path: str = LIB_PATH):
     lib.rt_get_option.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
     lib.rt_render.argtypes = [vp, vp, C.POINTER(RtStats)]
     lib.rt_render_device.argtypes = [vp, vp, C.POINTER(RtStats)]
+    lib.rt_render_device_noalloc.argtypes = [vp, vp, C.POINTER(RtStats)]
     lib.rt_trace_primary.argtypes = [vp, vp, vp, C.POINTER(RtStats)]
     lib.rt_trace_rays.argtypes = [vp, vp, C.c_int, vp, vp, C.POINTER(RtStats)]
     lib.rt_write_ppm.argtypes = [C.c_char_p, vp, C.c_int, C.c_int]
@@ -323,6 +324,13 @@ class PbrtEngine:
         self.uponPixelNumChange()
         self._check(self._lib.rt_render_device(self._h, C.c_void_p(device_ptr), C.byref(self.last_stats)),
                     "rt_render_device")
+        return self.last_stats
+
+    def renderDeviceNoAlloc(self, device_ptr: int) -> RtStats:
+        """renderDevice through rt_render_device_noalloc: scratch from the library's static device array, no hipMalloc,
+        nothing uploaded.  The caller's buffer must hold nx*ny*3 floats for the size of the last uponPixelNumChange()."""
+        self._check(self._lib.rt_render_device_noalloc(self._h, C.c_void_p(device_ptr), C.byref(self.last_stats)),
+                    "rt_render_device_noalloc")
         return self.last_stats
 
     def tracePrimary(self):
