@@ -8,6 +8,10 @@ aspect and spp (weak scaling: per-GPU pixel count fixed), tiles are interleaved 
 assembled on rank 0 with one RCCL reduce (each rank's frame is zero outside its tiles, so the sum is exact), which
 runs while the next frame renders into a second buffer.
 
+`python bench.py --gpus N` works as typed: a process started without torch.distributed's environment starts the N
+ranks itself (python -m torch.distributed.run, 127.0.0.1) BEFORE anything touches a GPU and relays rank 0's line.
+--strong is BASELINE.json configs[3]: the same scene at a FIXED 3840x2160, 1024 spp, tiles interleaved over the ranks.
+
 rays = closest-hit queries (hit() calls, reference pbrt_engine.cu:371), counted on the device.
 Scene, BVH and camera are resident in HBM before the timed region; the frame stays on the device.
 """
@@ -40,7 +44,8 @@ def cpu_baseline_and_bytes(tris, nodes, cam_args, nx, ny, ns, depth, stride, thr
     merge -- the reference has no CPU path) on a bounded pixel lattice of the same workload, on all the
     cores this process may use and on one thread (a 16x sparser lattice), and counts the box / triangle tests of an
     ordered, t-shrinking traversal of the same binary tree on the same rays, which define the algorithmic bytes per
-    ray B = 32*N_box + 48*N_tri + 36."""
+    ray B = 32*N_box + 48*N_tri + 36.  Also returns the oracle's image on that lattice: the checker
+    of the frame the GPU has just been timed on ("lattice_parity" in the line)."""
     from tests import oracle_lib  # the oracle is the checker / reported baseline here, never the product path
 
     o = oracle_lib.load()
@@ -48,9 +53,9 @@ def cpu_baseline_and_bytes(tris, nodes, cam_args, nx, ny, ns, depth, stride, thr
     cam = o.camera(cam_args["lookfrom"], cam_args["lookat"], 40.0, nx / ny, cam_args["aperture"], cam_args["dist_to_focus"])
     lat = (stride // 2, stride // 2, stride, stride)
     t0 = time.perf_counter()
-    _, c_ord = o.render(tris, nodes, mats, cam, nx, ny, ns, depth, mode=1, threads=threads, lattice=lat)
+    fb_ord, c_ord = o.render(tris, nodes, mats, cam, nx, ny, ns, depth, mode=1, threads=threads, lattice=lat)
     t1 = time.perf_counter()
-    _, c_ref = o.render(tris, nodes, mats, cam, nx, ny, ns, depth, mode=0, threads=threads, lattice=lat)
+    fb_ref, c_ref = o.render(tris, nodes, mats, cam, nx, ny, ns, depth, mode=0, threads=threads, lattice=lat)
     t2 = time.perf_counter()
     s1 = 4 * stride
     _, c_one = o.render(tris, nodes, mats, cam, nx, ny, ns, depth, mode=0, threads=1, lattice=(s1 // 2, s1 // 2, s1, s1))
@@ -73,27 +78,69 @@ def cpu_baseline_and_bytes(tris, nodes, cam_args, nx, ny, ns, depth, stride, thr
         "ordered_value": c_ord.rays / (t1 - t0) / 1e6,
         "ordered_tests_per_ray": {"box": n_box, "tri": n_tri},
     }
-    return base, bytes_per_ray
+    sub = (slice(lat[1], None, lat[3]), slice(lat[0], None, lat[2]))
+    assert fb_ord[sub].tobytes() == fb_ref[sub].tobytes()  # the oracle's two traversals give one image
+    return base, bytes_per_ray, fb_ref[sub].copy()
 
 
-def valu_issue(kernel_s):
-    """VALU issue occupancy of the render kernel from the committed counter passes (profiles/r01_pmc_summary.json,
-    tools/pmc_passes.sh): wave64 VALU instructions x 4 cycles over the cycles of 1024 SIMDs.  Not measured live."""
+PROFILE_ROUND = "r02"  # profiles/<round>_pmc_summary.json, <round>_lane_occupancy.jsonl: refreshed by tools/pmc_passes.sh
+SIMDS = 1024           # 256 CUs x 4
+PEAK_CLOCK_HZ = 2.4e9  # MI355X_MICROARCH.md, chip-level parameters
+VALU_ISSUE_CYCLES = 2  # cycles a SIMD needs per wave64 VALU instruction (same guide, wave scheduling)
+
+
+def committed_profile(workload_key):
+    """What the committed rocprofv3 passes say about the render kernel (tools/pmc_passes.sh -> tools/pmc_summary.py;
+    tools/trav_stats.py for the analysis build's per-ray counts).  These are NOT measured in this run: the record
+    carries the hash of the kernel sources it was taken from, and `profile_stale` says when they have changed since."""
+    from tools import profile_hash
+
+    out = {"source": f"profiles/{PROFILE_ROUND}_pmc_summary.json", "profile_stale": True}
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_summary.json")))
+        out["profile_stale"] = d.get("_meta", {}).get("source_hash") != profile_hash.kernel_source_hash()
         k = [x for x in d if "k_persistent<0, 1, 1, 6" in x][0]
         v = {c: x["per_dispatch"] for c, x in d[k].items()}
-        cycles = v["GRBM_GUI_ACTIVE"] / 8.0  # summed over 8 XCDs
-        return {"source": "profiles/r01_pmc_summary.json", "valu_insts_per_launch": v["SQ_INSTS_VALU"],
-                # 4 cycles per wave64 instruction; quarter-rate ones (rcp, sqrt, f64 divide steps) take longer, so the
-                # estimate can pass 1: read it as "the VALU pipe never idles"
-                "busy_frac": v["SQ_INSTS_VALU"] / 1024.0 * 4.0 / cycles,
-                # cycles a SIMD spends per wave64 VALU instruction; tools/micro/valu_rate.hip reaches 3.0-3.4 on the
-                # node test's instruction mix with no dependencies (profiles/r01_valu_issue_rate.jsonl)
-                "cycles_per_inst_per_simd": cycles * 1024.0 / v["SQ_INSTS_VALU"],
-                "lane_utilisation": v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0)}
-    except Exception:
-        return None
+        out["valu_insts_per_launch"] = v["SQ_INSTS_VALU"]
+        out["cycles_per_launch"] = v["GRBM_GUI_ACTIVE"] / 8.0  # the counter sums the 8 XCDs
+        out["lane_utilisation"] = v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0)
+        # SQ_LEVEL_WAVES reads 0 on gfx950 / ROCm 7.2: occupancy from wave-cycles (quad-cycles) over SIMD-cycles
+        out["waves_per_simd"] = v["SQ_WAVE_CYCLES"] * 4.0 / (out["cycles_per_launch"] * SIMDS)
+        if "TCC_HIT_sum" in v:
+            out["l2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
+        # gfx950: FETCH_SIZE (KB) counts half the bytes of 16-B-per-lane loads; WRITE_SIZE is exact.  These are the L2s'
+        # memory-side (fabric) requests: Infinity-Cache hits are INCLUDED, so this is an upper bound on HBM traffic.
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            out["fabric_bytes_per_launch"] = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
+            out["fabric_write_bytes_per_launch"] = v["WRITE_SIZE"] * 1024.0
+        out["workload"] = d.get("_meta", {}).get("workload")
+    except Exception as e:  # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"
+    try:
+        for line in open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_lane_occupancy.jsonl")):
+            t = json.loads(line)
+            if t.get("workload") == workload_key:
+                out["node_visits_per_ray"] = t["node_visits_per_ray"]
+                out["prim_tests_per_ray"] = t["prim_tests_per_ray"]
+    except Exception:  # noqa: BLE001
+        pass
+    return out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` typed by hand (or by the driver): start the N ranks as fresh child processes and relay
+    their output.  Runs before this process has imported torch or touched a GPU, and never replaces this process."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -102,21 +149,27 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", type=int, default=708, help="heightfield cells per side (708 -> 1 002 528 triangles)")
-    ap.add_argument("--nx", type=int, default=1920)
-    ap.add_argument("--ny", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--nx", type=int, default=None)
+    ap.add_argument("--ny", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--leaf", type=int, default=None)
     ap.add_argument("--box-mode", type=int, default=None)
     ap.add_argument("--kernel", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stride", type=int, default=8, help="CPU baseline lattice: every n-th pixel of every n-th row")
+    ap.add_argument("--strong", action="store_true",
+                    help="BASELINE.json configs[3]: a FIXED 3840x2160 frame at 1024 spp, tiles interleaved over the ranks "
+                         "(strong scaling; --nx/--ny/--spp override the size)")
     ap.add_argument("--sample-shard", action="store_true",
                     help="N > 1: split the SAMPLES of one fixed-size frame over ranks (salted streams, summed with one "
                          "all-reduce; SURVEY 8e's non-parity mode, strong scaling) instead of the tiles of a growing frame")
-    ap.add_argument("--verify", action="store_true",
-                    help="after timing, rank 0 renders the whole frame alone and compares it with the assembled one")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="N > 1, tiles: skip rank 0's untimed whole-frame render that the assembled frame is compared with")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -125,8 +178,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the trace loop has no CPU fallback")
     # RT_BENCH_REHEARSE=1: run the N > 1 code path on a box with ONE GPU (every rank on device 0, frame assembly over
@@ -148,12 +200,16 @@ def main():
     from rt_amd import engine as E
     from rt_amd import scenes
 
-    # weak scaling: pixels grow with N at fixed aspect
+    base_nx = args.nx or (3840 if args.strong else 1920)
+    base_ny = args.ny or (2160 if args.strong else 1080)
+    spp = args.spp or (1024 if args.strong else 64)
     sample_shard = args.sample_shard and world > 1
-    s = 1.0 if sample_shard else math.sqrt(world)
-    nx, ny = int(round(args.nx * s)), int(round(args.ny * s))
+    fixed_frame = args.strong or sample_shard
+    # weak scaling (the default): pixels grow with N at fixed aspect
+    s = 1.0 if fixed_frame else math.sqrt(world)
+    nx, ny = int(round(base_nx * s)), int(round(base_ny * s))
     tris = scenes.heightfield(args.grid)
-    ns_local, salt = E.sample_shard(rank, world, args.spp) if sample_shard else (args.spp, 0)
+    ns_local, salt = E.sample_shard(rank, world, spp) if sample_shard else (spp, 0)
     eng = rt_amd.PbrtEngine(nx, ny, ns_local, device=local_rank)
     if sample_shard:
         eng.setOption(E.OPT_SEED_SALT, salt)
@@ -172,7 +228,7 @@ def main():
     eng.setCamera(**scenes.BENCH_CAMERA)
     if not sample_shard:
         eng.setShard(rank, world)
-    kk = float(np.float32(1.0 / float(np.float32(args.spp))))
+    kk = float(np.float32(1.0 / float(np.float32(spp))))
     # Two frame buffers: frame k is assembled on rank 0 (RCCL's stream) while frame k + 1 renders (the library's
     # stream), so the exchange costs the job one reduce at the end, not one per frame.
     fbs = [torch.zeros((ny, nx, 3), dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(2 if world > 1 else 1)]
@@ -239,58 +295,75 @@ def main():
         rays_total = rays_local
 
     assembled_ok = None
-    if args.verify and world > 1 and rank == 0 and not sample_shard:
-        whole = torch.zeros_like(fb)
+    if world > 1 and rank == 0 and not sample_shard and not args.no_verify:
+        whole = torch.zeros_like(fb)  # untimed: rank 0 renders the whole frame alone
         eng.setShard(0, 1)
         eng.renderDevice(whole.data_ptr())
         eng.setShard(rank, world)
         assembled_ok = bool(torch.equal(whole, fb))
+        del whole
 
     if rank == 0:
         value = rays_total / elapsed / 1e6
         rays_per_launch = rays_local / args.steps
         kernel_s = float(np.mean(kernel_ms)) / 1e3
+        frame_cpu = fb.cpu().numpy() if (world == 1 and not args.no_cpu_baseline) else None
         # primary-only rate on the same scene (not the headline; reported beside it)
         eng.setShard(0, 1)
-        eng.setNx(args.nx), eng.setNy(args.ny)
+        eng.setNx(base_nx), eng.setNy(base_ny)
         eng.tracePrimary()
         eng.tracePrimary()
         prim = {"mrays_s": eng.last_stats.rays / (eng.last_stats.kernel_ms / 1e3) / 1e6, "kernel_ms": eng.last_stats.kernel_ms,
-                "frame": f"{args.nx}x{args.ny}x1"}
-        cpu, bytes_per_ray = None, None
-        if world == 1 and not args.no_cpu_baseline:
+                "frame": f"{base_nx}x{base_ny}x1"}
+        cpu, bytes_per_ray, lattice_parity = None, None, None
+        if frame_cpu is not None:
             threads = max(1, min(16, os.cpu_count() or 1))
-            cpu, bytes_per_ray = cpu_baseline_and_bytes(tris, eng.getBvhNodes(), scenes.BENCH_CAMERA, args.nx, args.ny,
-                                                        args.spp, args.depth, args.cpu_stride, threads)
-        roof = None
-        bytes_source = "counted live by the oracle's ordered traversal on the CPU sample"
-        if bytes_per_ray is None:  # N > 1 or --no-cpu-baseline: the committed N = 1 count of the same scene and camera
-            try:
-                committed = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_line.json")))
-                bytes_per_ray = committed["roofline"]["algorithmic_bytes_per_ray"]
-                bytes_source = "profiles/r01_bench_line.json (N = 1 run of the same scene, camera, spp and depth)"
-            except Exception:
-                bytes_per_ray = None
+            # the CPU leg runs at most 64 spp of the frame's pixels (a bounded sample of the same workload); the
+            # frame the GPU was timed on is compared with the oracle's only when that IS the frame's sample count
+            cpu_spp = min(spp, 64)
+            st_ = args.cpu_stride * (2 if nx * ny > 1920 * 1080 else 1)  # the same ~32 400 pixels on a 4K frame
+            cpu, bytes_per_ray, lat_img = cpu_baseline_and_bytes(tris, eng.getBvhNodes(), scenes.BENCH_CAMERA, nx, ny, cpu_spp,
+                                                                 args.depth, st_, threads)
+            if cpu_spp == spp:
+                lattice_parity = bool(frame_cpu[st_ // 2::st_, st_ // 2::st_].tobytes() == lat_img.tobytes())
+        workload_key = f"g{args.grid}_{nx}x{ny}x{spp}_d{args.depth}"
+        prof = committed_profile(workload_key)
+        same_workload = prof.get("workload") == workload_key and world == 1
+        roof = {"kernel": "k_persistent<0,1,1,6,false> (render: quantized 4-wide nodes, speculative traversal, rounds)",
+                "kernel_ms": kernel_s * 1e3, "rays_per_launch": rays_per_launch,
+                "committed_profile": prof}
+        if same_workload and "valu_insts_per_launch" in prof:
+            # What binds this kernel is vector-instruction ISSUE, not HBM: wave64 VALU instructions per
+            # launch (rocprofv3 SQ_INSTS_VALU, committed profile of these sources) over this run's kernel time, against
+            # 1024 SIMDs issuing one per 2 cycles at the 2.4 GHz peak clock.
+            achieved = prof["valu_insts_per_launch"] / kernel_s / 1e9
+            peak = SIMDS * PEAK_CLOCK_HZ / VALU_ISSUE_CYCLES / 1e9
+            roof.update({"bound": "valu_issue", "achieved": achieved, "peak": peak, "unit": "G wave64-inst/s", "frac": achieved / peak,
+                         "lane_utilisation": prof.get("lane_utilisation"),
+                         "useful_lane_frac": achieved / peak * prof.get("lane_utilisation", 0.0),
+                         "waves_per_simd": prof.get("waves_per_simd")})
+        else:
+            roof.update({"bound": "valu_issue", "achieved": None, "peak": SIMDS * PEAK_CLOCK_HZ / VALU_ISSUE_CYCLES / 1e9,
+                         "unit": "G wave64-inst/s", "frac": None,
+                         "note": "no committed counter pass for this workload / rank count: see profiles/"})
+        # memory side, secondary: bytes the DEVICE tree makes a ray touch (64-B quantized node per visit, 48-B primitive
+        # per test, 28 B ray in + 8 B hit out), against HBM peak; and the L2s' fabric traffic from the counter passes
+        mem = {"peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        if "node_visits_per_ray" in prof:
+            dev_bytes = 64.0 * prof["node_visits_per_ray"] + 48.0 * prof["prim_tests_per_ray"] + 36.0
+            mem.update({"device_bytes_per_ray": dev_bytes, "achieved": dev_bytes * rays_per_launch / kernel_s / 1e9,
+                        "frac": dev_bytes * rays_per_launch / kernel_s / 1e9 / HBM_PEAK_GBS})
+        if same_workload and "fabric_bytes_per_launch" in prof:
+            mem["fabric_traffic_bytes_per_launch"] = prof["fabric_bytes_per_launch"]
+            mem["fabric_traffic_gbs"] = prof["fabric_bytes_per_launch"] / kernel_s / 1e9
+            mem["fabric_traffic_note"] = "L2-side fabric requests, Infinity-Cache hits included: an upper bound on HBM bytes"
         if bytes_per_ray is not None:
-            achieved = bytes_per_ray * rays_per_launch / kernel_s / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))
-                    key = f"g{args.grid}_{args.nx}x{args.ny}x{args.spp}_d{args.depth}"
-                    traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "kernel": "k_persistent<0,1,1,6,false> (render, quantized nodes, speculative, 8 rounds)",
-                    "kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_ray": bytes_per_ray, "bytes_per_ray_source": bytes_source,
-                    "rays_per_launch": rays_per_launch,
-                    # frac > 1 is not an error: SURVEY 8d prices every box test of a binary-tree traversal at 32 HBM
-                    # bytes, while the device BVH (30 MB of nodes) is served from L2 / Infinity Cache.
-                    # What binds the kernel is VALU issue; its measured share comes from the committed PMC passes.
-                    "measured_hbm_gbs": (traffic / kernel_s / 1e9) if traffic else None,
-                    "valu_issue": valu_issue(kernel_s)}
+            # SURVEY 8d's figure: an ordered t-shrinking traversal of the reference's BINARY tree, counted live by the
+            # oracle on the CPU sample.  Kept for reference: it does not describe this kernel (its frac passes 1).
+            mem["algorithmic_bytes_per_ray_binary_tree"] = bytes_per_ray
+            mem["binary_tree_frac"] = bytes_per_ray * rays_per_launch / kernel_s / 1e9 / HBM_PEAK_GBS
+        roof["hbm"] = mem
+        roof["traffic"] = mem.get("fabric_traffic_bytes_per_launch")
         line = {
             "metric": "Mrays/s (node) on 1M-tri BVH; ms/frame at 1080p",
             "value": value,
@@ -300,13 +373,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong" if sample_shard else "weak",
+            "scaling": "strong" if fixed_frame else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks on one GPU, gloo; not a measurement)",
             "config": {"workload": f"heightfield G={args.grid} ({tris.shape[0]} triangles), diffuse path tracing, "
-                                   f"{nx}x{ny}, {args.spp} spp, max depth {args.depth}",
-                       "triangles": int(tris.shape[0]), "frame": f"{nx}x{ny}", "spp": args.spp, "max_depth": args.depth,
+                                   f"{nx}x{ny}, {spp} spp, max depth {args.depth}",
+                       "triangles": int(tris.shape[0]), "frame": f"{nx}x{ny}", "spp": spp, "max_depth": args.depth,
                        "parallelism": (f"sample-pass x{world} (salted streams; not the parity path)" if sample_shard
                                        else f"tile-interleaved x{world}"), "bvh_build_s": build_s,
                        "wide_nodes": int(eng.last_stats.wide_nodes), "lds_stack_entries": int(eng.last_stats.stack_entries)},
@@ -314,6 +387,8 @@ def main():
             "cpu_baseline": cpu,
             "primary": prim,
         }
+        if lattice_parity is not None:
+            line["lattice_parity"] = lattice_parity  # the timed frame's lattice == the oracle's image, byte for byte
         if assembled_ok is not None:
             line["assembled_frame_equals_single_gpu_frame"] = assembled_ok
         print(json.dumps(line), flush=True)

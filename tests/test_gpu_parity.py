@@ -655,14 +655,64 @@ def test_full_size_1m_tris_lattice(oracle):
     eng.close()
 
 
-@pytest.mark.skipif(not os.environ.get("RT_BIG_GRID"), reason="set RT_BIG_GRID=7072 for the 100M-triangle case (minutes, ~100 GB of host memory)")
+def test_bench_frame_64spp_lattice(oracle):
+    """BASELINE config 3 exactly as bench.py times it: 1 002 530 triangles, 1920x1080, 64 spp (eight tapered rounds of
+    11, 11, 10, 9, 8, 7, 5, 3 samples), depth 8.  The frame against the oracle on every 16th pixel of every 16th row,
+    bit for bit (bench.py makes the same comparison on its own timed frame: "lattice_parity")."""
+    tris = scenes.heightfield(708)
+    eng = _engine(tris, 1920, 1080, 64, 8, scenes.BENCH_CAMERA)
+    fb = eng.render()
+    assert 200_000_000 < eng.last_stats.rays < 400_000_000
+    nodes = eng.getBvhNodes()
+    cam = scenes.BENCH_CAMERA
+    ocam = oracle.camera(cam["lookfrom"], cam["lookat"], 40.0, 1920 / 1080, 0.0, 10.0)
+    lat = (8, 8, 16, 16)
+    fb_o, cnt = oracle.render(tris, nodes, oracle.material_table(), ocam, 1920, 1080, 64, 8, mode=1, threads=16, lattice=lat)
+    sub = (slice(lat[1], None, lat[3]), slice(lat[0], None, lat[2]))
+    assert cnt.rays > 1_000_000
+    assert fb[sub].tobytes() == fb_o[sub].tobytes()
+    eng.close()
+
+
+def test_cfg4_4k_frame_tile_sharded(oracle):
+    """BASELINE config 4's frame and partitioning on one GPU: the 1 M-triangle scene at 3840x2160 (spp reduced to 2
+    for the test), rendered as 2, 4 and 8 tile-interleaved shards (RT_OPT_SHARD_RANK / WORLD), each shard what one
+    rank of bench.py --strong renders.  The shards' sum -- what the RCCL reduce computes, x + 0 -- equals the
+    single-context frame bit for bit, ray counts add up, and the frame equals the oracle's on a sparse lattice."""
+    tris = scenes.heightfield(708)
+    nx, ny, ns, depth = 3840, 2160, 2, 8
+    eng = _engine(tris, nx, ny, ns, depth, scenes.BENCH_CAMERA)
+    whole = eng.render()
+    rays = eng.last_stats.rays
+    for world in (2, 4, 8):
+        acc = np.zeros_like(whole)
+        total = 0
+        for rank in range(world):
+            eng.setShard(rank, world)
+            part = eng.render()
+            total += eng.last_stats.rays
+            acc += part
+        assert total == rays, world
+        assert acc.tobytes() == whole.tobytes(), world
+    nodes = eng.getBvhNodes()
+    cam = scenes.BENCH_CAMERA
+    ocam = oracle.camera(cam["lookfrom"], cam["lookat"], 40.0, nx / ny, 0.0, 10.0)
+    lat = (13, 7, 48, 48)
+    fb_o, _ = oracle.render(tris, nodes, oracle.material_table(), ocam, nx, ny, ns, depth, mode=1, threads=16, lattice=lat)
+    sub = (slice(lat[1], None, lat[3]), slice(lat[0], None, lat[2]))
+    assert whole[sub].tobytes() == fb_o[sub].tobytes()
+    eng.close()
+
+
 def test_big_scene_cfg5(oracle):
-    """BASELINE config 5 on one GPU: a G x G heightfield (G=7072 -> 100 026 370 triangles), 1080p, 16 spp, depth 8,
-    BVH replicated per GPU.  The frame is checked against the oracle on a sparse pixel lattice (the oracle traverses
-    the product's reference-tree nodes; its own serial builder would take tens of minutes at this size)."""
+    """BASELINE config 5's kind of scene on one GPU: a G x G heightfield far beyond the caches, 1080p, 16 spp, depth 8,
+    BVH replicated per GPU.  Default G = 2236 (9 999 394 triangles: 1.5 GB of records, seconds to build);
+    RT_BIG_GRID=7072 runs the full 100 026 370 triangles (minutes, ~100 GB of host memory).  The frame is checked
+    against the oracle on a sparse pixel lattice (the oracle traverses the product's reference-tree nodes; its own
+    serial builder would take tens of minutes at the full size)."""
     import time
 
-    G = int(os.environ["RT_BIG_GRID"])
+    G = int(os.environ.get("RT_BIG_GRID", "2236"))
     t0 = time.time()
     tris = scenes.heightfield(G)
     t1 = time.time()
@@ -689,6 +739,31 @@ def test_big_scene_cfg5(oracle):
     sub = (slice(3, None, 20), slice(3, None, 20))
     assert (ids[sub] != ids_o[sub]).sum() == 0 and ts[sub].tobytes() == ts_o[sub].tobytes()
     eng.close()
+
+
+def test_bench_two_ranks_as_typed(tmp_path):
+    """`python bench.py --gpus 2 ...` as the driver types it, with no torch.distributed environment: the process starts
+    its two ranks itself and relays rank 0's line.  Rehearsed on this one GPU (RT_BENCH_REHEARSE=1: both ranks on
+    device 0, assembly over gloo): the line reports n_gpus, the scaling kind and that the assembled frame equals the
+    frame one context renders alone -- weak scaling (the frame grows) and --strong (config 4's fixed frame, small here)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RT_BENCH_REHEARSE"] = "1"
+    for extra, scaling, frame in ((["--nx", "320", "--ny", "180", "--spp", "4"], "weak", "453x255"),
+                                  (["--strong", "--nx", "384", "--ny", "216", "--spp", "6"], "strong", "384x216")):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                              "--grid", "64", "--no-cpu-baseline"] + extra, env=env, cwd=tmp_path, capture_output=True,
+                             text=True, timeout=280)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, out.stdout
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["config"]["frame"] == frame
+        assert line["assembled_frame_equals_single_gpu_frame"] is True
+        assert line["value"] > 0 and line["steps"] == 2
 
 
 def test_console_session_default_scene(oracle, tmp_path):

@@ -122,10 +122,17 @@ def main():
                               "mrays_s": eng.last_stats.rays / eng.last_stats.kernel_ms / 1e3}), flush=True)
         eng._check(eng._lib.rt_test_dump_rays(eng._h, 0), "rt_test_dump_rays")
         return
+    from tools import profile_hash
+
     d = stats(eng)
     d.update(kind="render", kernel_ms=eng.last_stats.kernel_ms, rays=int(eng.last_stats.rays))
     d["node_steps_per_ray"] = d["node_lanes"] / d["rays"]
     d["leaf_tests_per_ray"] = d["leaf_lanes"] / d["rays"]
+    # what bench.py's roofline object reads: per-ray work of the device tree, keyed by workload and source hash
+    d["workload"] = f"g{args.grid}_{args.nx}x{args.ny}x{args.spp}_d{args.depth}"
+    d["node_visits_per_ray"] = d["node_steps_per_ray"]
+    d["prim_tests_per_ray"] = d["leaf_prims"] / d["rays"]
+    d["source_hash"] = profile_hash.kernel_source_hash()
     print(json.dumps(d), flush=True)
     eng.tracePrimary()
     d = stats(eng)
