@@ -232,6 +232,10 @@ int rt_test_trav_stats(rt_ctx *ctx, uint64_t out[40]);
  * takes when taking a ray costs nothing but its loads (tools/trav_stats.py --replay). */
 int rt_test_dump_rays(rt_ctx *ctx, uint64_t capacity);
 int rt_test_trace_dumped(rt_ctx *ctx, rt_stats *stats);
+/* Analysis builds only: re-order the recorded rays on the host -- mode 1: by origin cell (128^3 Morton code), then
+ * direction octant; mode 2: by octant, then cell -- the most coherent order any ray-sorting scheme could hand the
+ * traversal kernel; rt_test_trace_dumped then prices it (tools/trav_stats.py --replay ... --sort). */
+int rt_test_sort_dumped(rt_ctx *ctx, int mode);
 
 /* Analysis builds only: for every wave of the last render, on the constant 100 MHz device clock: out[3 w] = start,
  * out[3 w + 1] = end, out[3 w + 2] = when it first found every band handed out; for the first n_waves waves; the first

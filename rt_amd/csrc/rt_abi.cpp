@@ -1174,6 +1174,55 @@ int rt_test_trace_dumped(rt_ctx *c, rt_stats *st) {
     return rc;
 }
 
+int rt_test_sort_dumped(rt_ctx *c, int mode) {
+    if (!c) return RT_E_ARG;
+#ifdef RT_TRAV_STATS
+    RT_TRY
+    if (!c->d_ray_dump) return fail(c, RT_E_ARG, "no recorded rays: rt_test_dump_rays, then render");
+    if (mode < 1 || mode > 2) return fail(c, RT_E_ARG, "sort mode 1 (origin cell, then octant) or 2 (octant, then origin cell)");
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned long long n = 0;
+    HIPCHK(c, hipMemcpy(&n, c->d_ray_dump_count, sizeof(n), hipMemcpyDeviceToHost));
+    if (n > c->ray_dump_cap) n = c->ray_dump_cap;
+    if (n == 0 || n > 0x7FFFFFFFull) return fail(c, RT_E_LIMIT, "recorded ray count out of range");
+    std::vector<float> rays(6 * (size_t)n), sorted(6 * (size_t)n);
+    HIPCHK(c, hipMemcpy(rays.data(), c->d_ray_dump, rays.size() * sizeof(float), hipMemcpyDeviceToHost));
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    for (size_t i = 0; i < n; i++)
+        for (int a = 0; a < 3; a++) {
+            const float v = rays[6 * i + a];
+            if (v < lo[a]) lo[a] = v;
+            if (v > hi[a]) hi[a] = v;
+        }
+    auto spread = [](uint32_t v) { // 7 bits -> every third bit
+        uint32_t r = 0;
+        for (int b = 0; b < 7; b++) r |= ((v >> b) & 1u) << (3 * b);
+        return r;
+    };
+    std::vector<uint64_t> keys(n);
+    for (size_t i = 0; i < n; i++) {
+        uint32_t cell = 0, oct = 0;
+        for (int a = 0; a < 3; a++) {
+            const float ext = hi[a] - lo[a];
+            int q = ext > 0.0f ? (int)((rays[6 * i + a] - lo[a]) / ext * 128.0f) : 0;
+            q = q < 0 ? 0 : (q > 127 ? 127 : q);
+            cell |= spread((uint32_t)q) << a;
+            oct |= (rays[6 * i + 3 + a] < 0.0f ? 1u : 0u) << a;
+        }
+        const uint32_t key = mode == 1 ? (cell << 3) | oct : (oct << 21) | cell;
+        keys[i] = ((uint64_t)key << 32) | (uint64_t)i;
+    }
+    std::sort(keys.begin(), keys.end());
+    for (size_t i = 0; i < n; i++) std::memcpy(&sorted[6 * i], &rays[6 * (size_t)(uint32_t)keys[i]], 6 * sizeof(float));
+    HIPCHK(c, hipMemcpy(c->d_ray_dump, sorted.data(), sorted.size() * sizeof(float), hipMemcpyHostToDevice));
+    return RT_OK;
+    RT_CATCH(c)
+#else
+    (void)mode;
+    return fail(c, RT_E_UNSUPPORTED, "built without RT_TRAV_STATS (make STATS=1 builds librt_amd_stats.so)");
+#endif
+}
+
 int rt_test_sincosf(float x, float *s, float *c) {
     if (!s || !c) return RT_E_ARG;
     double sd, cd;

@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "rt_set_option", "rt_get_option", "rt_render", "rt_render_device", "rt_trace_primary", "rt_trace_rays",
     "rt_write_ppm", "rt_test_glibc_rand", "rt_test_introsort", "rt_test_build_bvh", "rt_test_wide_layout", "rt_test_tile_owner", "rt_test_fastdiv",
     "rt_test_trav_stats", "rt_test_sincosf", "rt_set_texture", "rt_trace_rays_device", "rt_test_dump_rays", "rt_test_wave_times",
-    "rt_test_trace_dumped", "rt_render_device_noalloc",
+    "rt_test_trace_dumped", "rt_render_device_noalloc", "rt_test_sort_dumped",
 ]
 
 
@@ -103,6 +103,7 @@ def load_library(path: str = LIB_PATH):
     lib.rt_test_dump_rays.argtypes = [vp, C.c_uint64]
     lib.rt_test_wave_times.argtypes = [vp, vp, C.c_uint64]
     lib.rt_test_trace_dumped.argtypes = [vp, C.POINTER(RtStats)]
+    lib.rt_test_sort_dumped.argtypes = [vp, C.c_int]
     lib.rt_set_option.argtypes = [vp, C.c_int, C.c_int64]
     lib.rt_get_option.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
     lib.rt_render.argtypes = [vp, vp, C.POINTER(RtStats)]

@@ -64,9 +64,13 @@ def main():
     ap.add_argument("--occ", type=int, default=None)
     ap.add_argument("--waves", type=int, default=None)
     ap.add_argument("--tail", type=int, default=None)
+    ap.add_argument("--pchunk", type=int, default=None)
+    ap.add_argument("--pwaves", type=int, default=None)
     ap.add_argument("--primary-only", action="store_true", help="with --wave-times: the primary-ray kernel instead of the render")
     ap.add_argument("--wave-times", action="store_true", help="when each wave of the render ends (share of waves still running over time)")
     ap.add_argument("--queue-waves", type=lambda t: [int(x) for x in t.split(",")], default=[16])
+    ap.add_argument("--sort", type=lambda t: [int(x) for x in t.split(",")], default=[0],
+                    help="with --replay: ray orders to replay: 0 = as the waves started them, 1 = sorted by origin cell then octant, 2 = by octant then cell")
     ap.add_argument("--replay", type=str, default=None, metavar="T1,T2,...",
                     help="record the frame's rays and trace them again with the ray-array kernel at these hand-out thresholds")
     args = ap.parse_args()
@@ -78,7 +82,8 @@ def main():
     if args.leaf is not None:
         eng.setOption(E.OPT_LEAF_SIZE, args.leaf)
     for opt, v in ((E.OPT_KERNEL, args.kernel), (E.OPT_SHADE_BATCH, args.shade), (E.OPT_SWAP_BATCH, args.swap),
-                   (E.OPT_OCCUPANCY, args.occ), (E.OPT_WAVES_PER_CU, args.waves), (E.OPT_TAIL_SPLIT, args.tail)):
+                   (E.OPT_OCCUPANCY, args.occ), (E.OPT_WAVES_PER_CU, args.waves), (E.OPT_TAIL_SPLIT, args.tail),
+                   (E.OPT_PRIMARY_CHUNK, args.pchunk), (E.OPT_PRIMARY_WAVES, args.pwaves)):
         if v is not None:
             eng.setOption(opt, v)
     eng.setTriangles(scenes.heightfield(args.grid))
@@ -112,14 +117,18 @@ def main():
     eng.render()
     if args.replay:
         rays, render_ms = int(eng.last_stats.rays), eng.last_stats.kernel_ms
-        for thr, qw in [(int(x), w) for x in args.replay.split(",") for w in args.queue_waves]:
-            eng.setOption(E.OPT_QUEUE_THRESHOLD, thr)
-            eng.setOption(E.OPT_QUEUE_WAVES, qw)
-            for _ in range(2):
-                eng._check(eng._lib.rt_test_trace_dumped(eng._h, C.byref(eng.last_stats)), "rt_test_trace_dumped")
-            print(json.dumps({"kind": "replay", "threshold": thr, "queue_waves": qw, "rays": int(eng.last_stats.rays), "render_rays": rays,
-                              "render_ms_stats_build": render_ms, "replay_ms": eng.last_stats.kernel_ms,
-                              "mrays_s": eng.last_stats.rays / eng.last_stats.kernel_ms / 1e3}), flush=True)
+        for order in sorted(args.sort):  # 0 first: sorting rewrites the recorded rays in place
+            if order:
+                eng._check(eng._lib.rt_test_sort_dumped(eng._h, order), "rt_test_sort_dumped")
+            for thr, qw in [(int(x), w) for x in args.replay.split(",") for w in args.queue_waves]:
+                eng.setOption(E.OPT_QUEUE_THRESHOLD, thr)
+                eng.setOption(E.OPT_QUEUE_WAVES, qw)
+                for _ in range(2):
+                    eng._check(eng._lib.rt_test_trace_dumped(eng._h, C.byref(eng.last_stats)), "rt_test_trace_dumped")
+                print(json.dumps({"kind": "replay", "order": ["wave start order", "origin cell, octant", "octant, origin cell"][order],
+                                  "threshold": thr, "queue_waves": qw, "rays": int(eng.last_stats.rays), "render_rays": rays,
+                                  "spp": args.spp, "render_ms_stats_build": render_ms, "replay_ms": eng.last_stats.kernel_ms,
+                                  "mrays_s": eng.last_stats.rays / eng.last_stats.kernel_ms / 1e3}), flush=True)
         eng._check(eng._lib.rt_test_dump_rays(eng._h, 0), "rt_test_dump_rays")
         return
     from tools import profile_hash
