@@ -164,6 +164,10 @@ def main():
     ap.add_argument("--sample-shard", action="store_true",
                     help="N > 1: split the SAMPLES of one fixed-size frame over ranks (salted streams, summed with one "
                          "all-reduce; SURVEY 8e's non-parity mode, strong scaling) instead of the tiles of a growing frame")
+    ap.add_argument("--share-scene", choices=["auto", "on", "off"], default="auto",
+                    help="N > 1: rank 0 builds the scene once and the other ranks import its device layout from a shared "
+                         "mapping in /dev/shm (rt_export_scene / rt_import_scene) instead of every rank generating, building "
+                         "and laying out its own copy; auto = for scenes of more than 4 M triangles")
     ap.add_argument("--no-verify", action="store_true",
                     help="N > 1, tiles: skip rank 0's untimed whole-frame render that the assembled frame is compared with")
     args = ap.parse_args()
@@ -208,7 +212,8 @@ def main():
     # weak scaling (the default): pixels grow with N at fixed aspect
     s = 1.0 if fixed_frame else math.sqrt(world)
     nx, ny = int(round(base_nx * s)), int(round(base_ny * s))
-    tris = scenes.heightfield(args.grid)
+    n_tris = 2 * args.grid * args.grid + 2
+    share = world > 1 and (args.share_scene == "on" or (args.share_scene == "auto" and n_tris > 4_000_000))
     ns_local, salt = E.sample_shard(rank, world, spp) if sample_shard else (spp, 0)
     eng = rt_amd.PbrtEngine(nx, ny, ns_local, device=local_rank)
     if sample_shard:
@@ -220,9 +225,36 @@ def main():
         eng.setOption(E.OPT_BOX_MODE, args.box_mode)
     if args.kernel is not None:
         eng.setOption(E.OPT_KERNEL, args.kernel)
-    eng.setTriangles(tris)
+    tris = None
     t0 = time.perf_counter()
-    eng.buildBvh()
+    if not share or rank == 0:
+        tris = scenes.heightfield(args.grid)
+        assert tris.shape[0] == n_tris
+        eng.setTriangles(tris)
+        eng.buildBvh()
+    if share:
+        # One build per node: rank 0 writes the device layout into a file in /dev/shm (host memory, mapped by every
+        # rank), the others upload straight from the mapping.  BASELINE config 5 (100 M triangles) would otherwise cost
+        # every rank 14.8 GB of records, a 47 s all-core build and ~100 GB of host memory.
+        path = f"/dev/shm/rt_amd_scene_{os.environ.get('MASTER_PORT', '0')}_{args.grid}.bin"
+        size = torch.zeros(1, dtype=torch.int64)
+        if rank == 0:
+            size[0] = eng.exportSceneSize(0)
+            mm = np.memmap(path, dtype=np.uint8, mode="w+", shape=(int(size[0]),))
+            eng.exportScene(0, out=mm)
+            mm.flush()
+            del mm
+        if rehearse:
+            dist.broadcast(size, src=0)
+        else:
+            size = size.to(f"cuda:{local_rank}")
+            dist.broadcast(size, src=0)  # doubles as the barrier: the file is complete when rank 0 gets here
+            size = size.cpu()
+        if rank != 0:
+            eng.importScene(np.memmap(path, dtype=np.uint8, mode="r", shape=(int(size[0]),)))
+        dist.barrier()
+        if rank == 0:
+            os.unlink(path)
     build_s = time.perf_counter() - t0
     eng.setMaxDepth(args.depth)
     eng.setCamera(**scenes.BENCH_CAMERA)
@@ -377,9 +409,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks on one GPU, gloo; not a measurement)",
-            "config": {"workload": f"heightfield G={args.grid} ({tris.shape[0]} triangles), diffuse path tracing, "
+            "config": {"workload": f"heightfield G={args.grid} ({n_tris} triangles), diffuse path tracing, "
                                    f"{nx}x{ny}, {spp} spp, max depth {args.depth}",
-                       "triangles": int(tris.shape[0]), "frame": f"{nx}x{ny}", "spp": spp, "max_depth": args.depth,
+                       "triangles": n_tris, "frame": f"{nx}x{ny}", "spp": spp, "max_depth": args.depth,
+                       "scene_shared_from_rank0": bool(share),
                        "parallelism": (f"sample-pass x{world} (salted streams; not the parity path)" if sample_shard
                                        else f"tile-interleaved x{world}"), "bvh_build_s": build_s,
                        "wide_nodes": int(eng.last_stats.wide_nodes), "lds_stack_entries": int(eng.last_stats.stack_entries)},

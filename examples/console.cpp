@@ -127,7 +127,11 @@ int main(int argc, char **argv) {
                     else engine.uponPixelNumChange(); // ns reaches the library through rt_resize as well
                 } else {
                     const bool build = !(tokens.size() >= 2 && tokens[1] == "-cache");
-                    if (build) engine.setTriangles(gather(meshes));
+                    if (build) { // main.cpp:711-713 registers every mesh of the name-sorted collection with the engine
+                        std::vector<Mesh *> scene;
+                        for (const auto &kv : meshes) scene.push_back(kv.second.get());
+                        engine.addMesh(scene); // flattened by renderScene, "light" first (pbrt_engine.cu:167-178)
+                    }
                     const float from[3] = {cam.pos.x, cam.pos.y, cam.pos.z};
                     const float at[3] = {cam.pos.x + cam.front.x, cam.pos.y + cam.front.y, cam.pos.z + cam.front.z};
                     engine.setCamera(from, at, cam.zoom, cam.dist_to_focus, cam.aperture);
@@ -153,7 +157,8 @@ int main(int argc, char **argv) {
                         registerModel(meshes, plane_mesh(kind));
                         if (!dump && !texture0_set) { // the planes name texture 0 ("test01.png" in the reference)
                             const std::vector<unsigned char> t = default_texture();
-                            PbrtEngine::getInstance().setTexture(0, t.data(), 64, 64);
+                            PbrtEngine::getInstance().registerTexture(0, t.data(), 64, 64);
+                            PbrtEngine::getInstance().genTextures(); // pbrt_engine.h:133
                             texture0_set = true;
                         }
                     }

@@ -105,6 +105,19 @@ int rt_set_bvh_nodes(rt_ctx *ctx, const rt_bvh_node32 *nodes, int m);
 /* Read back the binary node array (m = 2n-1). cap = capacity of out in nodes. */
 int rt_get_bvh_nodes(rt_ctx *ctx, rt_bvh_node32 *out, int cap, int *m);
 
+/* The built device scene (wide nodes, re-ordered primitives, shading records, texture coordinates) as ONE relocatable
+ * block of bytes, so that a scene is built once per node and handed to the other GPUs' contexts instead of every rank
+ * flattening, building (pbrt_engine.cu:181-202 on every rank) and laying it out again: BASELINE config 5's 100 M
+ * triangles are 14.8 GB of records and a 47 s all-core build per rank otherwise.  No reference counterpart.
+ * rt_export_scene: out == NULL returns the size in *bytes; flags bit 0 = include the 128-byte float nodes
+ * (RT_OPT_NODE_FORMAT 0 / RT_OPT_KERNEL 0 need them), bit 1 = include the reference's binary node array (so that
+ * rt_get_bvh_nodes works on the importing side).  rt_import_scene replaces the context's scene with the block's
+ * (copied to the device during the call; the block may be a read-only shared mapping); materials, textures, camera
+ * and options are not part of it.  An imported scene cannot be re-laid-out: changing RT_OPT_LEAF_SIZE / BOX_MODE /
+ * TOPOLOGY / COLLAPSE afterwards is an error at the next render. */
+int rt_export_scene(rt_ctx *ctx, int flags, void *out, uint64_t cap, uint64_t *bytes);
+int rt_import_scene(rt_ctx *ctx, const void *blob, uint64_t bytes);
+
 /* One texture object (Texture::getTexture -> cudaCreateTextureObject, src/cxx/texture.cpp:45-86): RGBA8 texels, w*h*4
  * bytes, row 0 first, copied during the call.  Sampled as the reference's descriptor says: normalised coordinates,
  * wrap addressing, linear filtering, channels as byte/255 (utilities.cu:4-9); a lambertian or a diffusive_light
@@ -212,6 +225,13 @@ int rt_test_build_bvh(const rt_triangle148 *tris, int n, int64_t rand_calls_befo
  * depth, stack_entries}.  topology: bit 0 = RT_OPT_TOPOLOGY, bit 1 = RT_OPT_COLLAPSE. */
 int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size,
                         int box_mode, int topology, void *wide_nodes, void *quant_nodes, void *prims, int32_t info[4]);
+
+/* rt_export_scene's block from records and nodes alone, and a block's header (no GPU needed): info = {wide nodes,
+ * primitives, uv records, float nodes, binary nodes, total bytes, depth, stack entries, then the byte offsets of the
+ * six sections}; RT_E_ARG for a block that rt_import_scene would refuse. */
+int rt_test_scene_blob(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size, int box_mode,
+                       int topology, int flags, void *out, uint64_t cap, uint64_t *bytes);
+int rt_test_scene_blob_info(const void *blob, uint64_t bytes, uint64_t info[16]);
 
 /* The tile-sharding rule alone (no GPU needed): owner[j*nx+i] = rank that renders pixel (i, j) when the frame
  * is split over `world` contexts (RT_OPT_SHARD_RANK / RT_OPT_SHARD_WORLD). */

@@ -67,6 +67,8 @@ struct rt_ctx {
     std::vector<rt_bvh_node32> bnodes;
     WideBvh wide;
     bool scene_on_device = false;
+    bool imported = false;       // the device scene came from rt_import_scene: no triangle records, no host layout
+    size_t n_wide = 0, n_prims = 0; // sizes of the device scene (c->wide is empty for an imported one)
 
     void *d_nodes = nullptr, *d_qnodes = nullptr, *d_prims = nullptr, *d_shade = nullptr;
     DevMat *d_mats = nullptr;
@@ -207,7 +209,82 @@ int upload_scene(rt_ctx *c) {
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->scene_on_device = true;
+    c->imported = false;
+    c->n_wide = c->wide.qnodes.size();
+    c->n_prims = c->wide.prims.size();
     return RT_OK;
+}
+
+// ---- the built device scene as one relocatable block of bytes (rt_export_scene / rt_import_scene) ----
+// header (256 bytes), then the sections in this order, each starting on a multiple of 256 bytes:
+// quantised nodes, primitives, shading records, texture coordinates, [float nodes], [reference binary nodes]
+struct SceneBlobHeader {
+    char magic[8]; // "RTAMDSC1"
+    uint64_t n_wide, n_prims, n_uv, n_float_nodes, n_bnodes, total_bytes;
+    int32_t depth, stack_entries;
+    float pad;
+    int32_t reserved;
+};
+static_assert(sizeof(SceneBlobHeader) <= 256, "scene blob header");
+constexpr uint64_t kBlobAlign = 256;
+inline uint64_t blob_round(uint64_t b) { return (b + kBlobAlign - 1) / kBlobAlign * kBlobAlign; }
+struct SceneBlobLayout {
+    uint64_t qnodes, prims, shade, uv, fnodes, bnodes, total;
+};
+SceneBlobLayout blob_layout(const SceneBlobHeader &h) {
+    SceneBlobLayout L;
+    uint64_t at = kBlobAlign;
+    L.qnodes = at, at += blob_round(h.n_wide * sizeof(QuantNode));
+    L.prims = at, at += blob_round(h.n_prims * sizeof(DevPrim));
+    L.shade = at, at += blob_round(h.n_prims * sizeof(DevShade));
+    L.uv = at, at += blob_round(h.n_uv * sizeof(DevUV));
+    L.fnodes = at, at += blob_round(h.n_float_nodes * sizeof(WideNode));
+    L.bnodes = at, at += blob_round(h.n_bnodes * sizeof(rt_bvh_node32));
+    L.total = at;
+    return L;
+}
+// flags: bit 0 = with the 128-byte float nodes (RT_OPT_NODE_FORMAT 0 and kernel variant 0 need them), bit 1 = with the
+// reference's binary node array (rt_get_bvh_nodes on the importing side)
+int write_scene_blob(const WideBvh &w, const std::vector<rt_bvh_node32> &bnodes, int flags, void *out, uint64_t cap, uint64_t *bytes) {
+    SceneBlobHeader h;
+    std::memset(&h, 0, sizeof(h));
+    std::memcpy(h.magic, "RTAMDSC1", 8);
+    h.n_wide = w.qnodes.size();
+    h.n_prims = w.prims.size();
+    h.n_uv = w.uv.size();
+    h.n_float_nodes = (flags & 1) ? w.nodes.size() : 0;
+    h.n_bnodes = (flags & 2) ? bnodes.size() : 0;
+    h.depth = w.depth;
+    h.stack_entries = w.stack_entries;
+    h.pad = w.pad;
+    const SceneBlobLayout L = blob_layout(h);
+    h.total_bytes = L.total;
+    if (bytes) *bytes = L.total;
+    if (!out) return RT_OK; // size query
+    if (cap < L.total) return RT_E_ARG;
+    char *o = static_cast<char *>(out);
+    std::memset(o, 0, kBlobAlign);
+    std::memcpy(o, &h, sizeof(h));
+    std::memcpy(o + L.qnodes, w.qnodes.data(), h.n_wide * sizeof(QuantNode));
+    std::memcpy(o + L.prims, w.prims.data(), h.n_prims * sizeof(DevPrim));
+    std::memcpy(o + L.shade, w.shade.data(), h.n_prims * sizeof(DevShade));
+    if (h.n_uv) std::memcpy(o + L.uv, w.uv.data(), h.n_uv * sizeof(DevUV));
+    if (h.n_float_nodes) std::memcpy(o + L.fnodes, w.nodes.data(), h.n_float_nodes * sizeof(WideNode));
+    if (h.n_bnodes) std::memcpy(o + L.bnodes, bnodes.data(), h.n_bnodes * sizeof(rt_bvh_node32));
+    return RT_OK;
+}
+// checks a blob's header against its length; err names what is wrong
+bool read_scene_blob_header(const void *blob, uint64_t bytes, SceneBlobHeader &h, SceneBlobLayout &L, std::string &err) {
+    if (!blob || bytes < kBlobAlign) return err = "scene blob too short", false;
+    std::memcpy(&h, blob, sizeof(h));
+    if (std::memcmp(h.magic, "RTAMDSC1", 8) != 0) return err = "not a scene blob (bad magic)", false;
+    if (h.n_wide == 0 || h.n_prims == 0 || h.n_wide > ((uint64_t)1 << 26) || h.n_prims > 0x0FFFFFFFull ||
+        (h.n_uv != 0 && h.n_uv != h.n_prims) || (h.n_float_nodes != 0 && h.n_float_nodes != h.n_wide) ||
+        h.n_bnodes > 0x7FFFFFFFull || h.stack_entries < 1 || (uint64_t)h.stack_entries * 256 > 64 * 1024)
+        return err = "scene blob header out of range", false;
+    L = blob_layout(h);
+    if (L.total != h.total_bytes || bytes < L.total) return err = "scene blob truncated", false;
+    return true;
 }
 
 // the descriptor table follows every rt_set_texture at once (d_tex is allocated at rt_create), so that a render has
@@ -259,8 +336,16 @@ int ensure_fb(rt_ctx *c) {
 }
 
 int ready_to_trace(rt_ctx *c) {
-    if (c->tris.empty()) return fail(c, RT_E_ARG, "no scene: call rt_set_scene first");
-    if (c->bnodes.empty()) return fail(c, RT_E_ARG, "no BVH: call rt_build_bvh or rt_set_bvh_nodes first");
+    if (c->imported) {
+        if (!c->scene_on_device)
+            return fail(c, RT_E_ARG, "imported scene: a device-layout option changed and there are no triangle records to rebuild from; "
+                                     "import again or set the scene");
+        if (!c->d_nodes && (c->node_format == 0 || c->kernel_variant == 0))
+            return fail(c, RT_E_ARG, "imported scene carries no float nodes (export flag 1): RT_OPT_NODE_FORMAT 0 / RT_OPT_KERNEL 0 cannot run");
+    } else {
+        if (c->tris.empty()) return fail(c, RT_E_ARG, "no scene: call rt_set_scene first");
+        if (c->bnodes.empty()) return fail(c, RT_E_ARG, "no BVH: call rt_build_bvh or rt_set_bvh_nodes first");
+    }
     if (!c->scene_on_device) {
         int rc = upload_scene(c);
         if (rc) return rc;
@@ -308,8 +393,8 @@ void fill_stats(rt_ctx *c, rt_stats *st, uint64_t rays, float ms, double total_m
     st->rays = rays;
     st->kernel_ms = ms;
     st->total_ms = total_ms;
-    st->wide_nodes = c->wide.nodes.size();
-    st->prims = c->wide.prims.size();
+    st->wide_nodes = c->n_wide;
+    st->prims = c->n_prims;
     st->stack_entries = c->wide.stack_entries;
     st->reserved = 0;
 }
@@ -621,6 +706,7 @@ int rt_set_scene(rt_ctx *c, const rt_triangle148 *tris, int n) {
     c->tris.assign(tris, tris + n);
     c->bnodes.clear();
     free_scene(c);
+    c->imported = false;
     return RT_OK;
     RT_CATCH(c)
 }
@@ -867,7 +953,10 @@ int rt_render_device_noalloc(rt_ctx *c, float *fb_rgb_device, rt_stats *st) {
     double t0 = now_ms();
     if (!c->cam_set) return fail(c, RT_E_ARG, "no camera: call rt_set_camera first");
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->tris.empty() || c->bnodes.empty()) return fail(c, RT_E_ARG, "no scene / no BVH: call rt_set_scene and rt_build_bvh first");
+    if (!c->imported && (c->tris.empty() || c->bnodes.empty()))
+        return fail(c, RT_E_ARG, "no scene / no BVH: call rt_set_scene and rt_build_bvh first");
+    if (c->imported && !c->d_nodes && (c->node_format == 0 || c->kernel_variant == 0))
+        return fail(c, RT_E_ARG, "imported scene carries no float nodes");
     // everything a render reads must be resident already: this call uploads and allocates nothing
     if (!c->scene_on_device)
         return fail(c, RT_E_ARG, "the device scene is not resident (a layout option changed since the build): call rt_build_bvh, "
@@ -1074,6 +1163,94 @@ int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *
     if (prims) std::memcpy(prims, w.prims.data(), w.prims.size() * sizeof(DevPrim));
     return RT_OK;
     RT_CATCH(nullptr)
+}
+
+int rt_export_scene(rt_ctx *c, int flags, void *out, uint64_t cap, uint64_t *bytes) {
+    if (!c || !bytes) return RT_E_ARG;
+    RT_TRY
+    if (flags < 0 || flags > 3) return fail(c, RT_E_ARG, "export flags 0..3");
+    if (c->imported) return fail(c, RT_E_ARG, "an imported scene keeps no host copy to export: pass the block it came from on");
+    if (c->tris.empty() || c->bnodes.empty()) return fail(c, RT_E_ARG, "no scene / no BVH to export");
+    if (c->wide.qnodes.empty() || !c->scene_on_device) { // a layout option changed since the build: lay out again
+        HIPCHK(c, hipSetDevice(c->device));
+        int rc = upload_scene(c);
+        if (rc) return rc;
+    }
+    if (write_scene_blob(c->wide, c->bnodes, flags, out, cap, bytes) != RT_OK) return fail(c, RT_E_ARG, "export buffer too small");
+    return RT_OK;
+    RT_CATCH(c)
+}
+
+int rt_import_scene(rt_ctx *c, const void *blob, uint64_t bytes) {
+    if (!c) return RT_E_ARG;
+    RT_TRY
+    SceneBlobHeader h;
+    SceneBlobLayout L;
+    std::string err;
+    if (!read_scene_blob_header(blob, bytes, h, L, err)) return fail(c, RT_E_ARG, err);
+    HIPCHK(c, hipSetDevice(c->device));
+    const char *b = static_cast<const char *>(blob);
+    free_scene(c);
+    c->tris.clear();
+    c->tris.shrink_to_fit();
+    c->bnodes.clear();
+    c->wide = WideBvh();
+    c->imported = false;
+    HIPCHK(c, hipMalloc(&c->d_qnodes, h.n_wide * sizeof(QuantNode)));
+    HIPCHK(c, hipMalloc(&c->d_prims, h.n_prims * sizeof(DevPrim)));
+    HIPCHK(c, hipMalloc(&c->d_shade, h.n_prims * sizeof(DevShade)));
+    HIPCHK(c, hipMemcpy(c->d_qnodes, b + L.qnodes, h.n_wide * sizeof(QuantNode), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_prims, b + L.prims, h.n_prims * sizeof(DevPrim), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_shade, b + L.shade, h.n_prims * sizeof(DevShade), hipMemcpyHostToDevice));
+    if (h.n_uv) {
+        HIPCHK(c, hipMalloc(&c->d_uv, h.n_uv * sizeof(DevUV)));
+        HIPCHK(c, hipMemcpy(c->d_uv, b + L.uv, h.n_uv * sizeof(DevUV), hipMemcpyHostToDevice));
+        c->wide.uv.resize(h.n_uv); // kept on the host: which textures the scene names (check_textures)
+        std::memcpy(c->wide.uv.data(), b + L.uv, h.n_uv * sizeof(DevUV));
+        for (const DevUV &q : c->wide.uv)
+            if (q.tex < -1 || q.tex >= RT_TEX_NUM) {
+                free_scene(c);
+                return fail(c, RT_E_ARG, "scene blob names a texture index out of range");
+            }
+    }
+    if (h.n_float_nodes) {
+        HIPCHK(c, hipMalloc(&c->d_nodes, h.n_float_nodes * sizeof(WideNode)));
+        HIPCHK(c, hipMemcpy(c->d_nodes, b + L.fnodes, h.n_float_nodes * sizeof(WideNode), hipMemcpyHostToDevice));
+    }
+    if (h.n_bnodes) c->bnodes.assign(reinterpret_cast<const rt_bvh_node32 *>(b + L.bnodes), reinterpret_cast<const rt_bvh_node32 *>(b + L.bnodes) + h.n_bnodes);
+    c->wide.depth = h.depth;
+    c->wide.stack_entries = h.stack_entries;
+    c->wide.pad = h.pad;
+    c->n_wide = h.n_wide;
+    c->n_prims = h.n_prims;
+    c->imported = true;
+    c->scene_on_device = true;
+    return RT_OK;
+    RT_CATCH(c)
+}
+
+int rt_test_scene_blob(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size, int box_mode,
+                       int topology, int flags, void *out, uint64_t cap, uint64_t *bytes) {
+    if (!tris || !nodes || !bytes || flags < 0 || flags > 3 || topology < 0 || topology > 3) return RT_E_ARG;
+    RT_TRY
+    WideBvh w;
+    std::string err;
+    if (!make_device_layout(tris, n, nodes, m, leaf_size, box_mode, topology & 1, w, err, topology >> 1)) return RT_E_ARG;
+    std::vector<rt_bvh_node32> bn(nodes, nodes + m);
+    return write_scene_blob(w, bn, flags, out, cap, bytes);
+    RT_CATCH(nullptr)
+}
+
+int rt_test_scene_blob_info(const void *blob, uint64_t bytes, uint64_t info[16]) {
+    if (!info) return RT_E_ARG;
+    SceneBlobHeader h;
+    SceneBlobLayout L;
+    std::string err;
+    if (!read_scene_blob_header(blob, bytes, h, L, err)) return RT_E_ARG;
+    const uint64_t v[16] = {h.n_wide, h.n_prims, h.n_uv, h.n_float_nodes, h.n_bnodes, h.total_bytes, (uint64_t)h.depth,
+                            (uint64_t)h.stack_entries, L.qnodes, L.prims, L.shade, L.uv, L.fnodes, L.bnodes, 0, 0};
+    std::memcpy(info, v, sizeof(v));
+    return RT_OK;
 }
 
 int rt_test_trav_stats(rt_ctx *c, uint64_t out[40]) {

@@ -159,6 +159,7 @@ class Mesh {
         m_fTranslationZ = p.z;
     }
 
+    const std::string &getName() const { return m_strName; }
     const Mesh *who() const { return m_ptrTopMesh ? m_ptrTopMesh : this; } // setTopMesh, mesh.h:104-144
     int getMatType() const { return who()->matType; }
     bool isSphere() const { return who()->m_bIsSphere; }

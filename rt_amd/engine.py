@@ -72,7 +72,8 @@ ABI_SYMBOLS = [
     "rt_set_option", "rt_get_option", "rt_render", "rt_render_device", "rt_trace_primary", "rt_trace_rays",
     "rt_write_ppm", "rt_test_glibc_rand", "rt_test_introsort", "rt_test_build_bvh", "rt_test_wide_layout", "rt_test_tile_owner", "rt_test_fastdiv",
     "rt_test_trav_stats", "rt_test_sincosf", "rt_set_texture", "rt_trace_rays_device", "rt_test_dump_rays", "rt_test_wave_times",
-    "rt_test_trace_dumped", "rt_render_device_noalloc", "rt_test_sort_dumped",
+    "rt_test_trace_dumped", "rt_render_device_noalloc", "rt_test_sort_dumped", "rt_export_scene", "rt_import_scene",
+    "rt_test_scene_blob", "rt_test_scene_blob_info",
 ]
 
 
@@ -104,6 +105,10 @@ def load_library(path: str = LIB_PATH):
     lib.rt_test_wave_times.argtypes = [vp, vp, C.c_uint64]
     lib.rt_test_trace_dumped.argtypes = [vp, C.POINTER(RtStats)]
     lib.rt_test_sort_dumped.argtypes = [vp, C.c_int]
+    lib.rt_export_scene.argtypes = [vp, C.c_int, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.rt_import_scene.argtypes = [vp, vp, C.c_uint64]
+    lib.rt_test_scene_blob.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.rt_test_scene_blob_info.argtypes = [vp, C.c_uint64, vp]
     lib.rt_set_option.argtypes = [vp, C.c_int, C.c_int64]
     lib.rt_get_option.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
     lib.rt_render.argtypes = [vp, vp, C.POINTER(RtStats)]
@@ -188,6 +193,33 @@ def host_wide_layout(tris: np.ndarray, nodes: np.ndarray, leaf_size: int = 1, bo
     return wide, prims, int(info[2]), int(info[3])
 
 
+def host_scene_blob(tris: np.ndarray, nodes: np.ndarray, leaf_size: int = 2, box_mode: int = 0, topology: int = 3, flags: int = 0) -> np.ndarray:
+    """rt_export_scene's block from records and reference nodes alone (no GPU): uint8 array."""
+    lib = load_library()
+    tris = np.ascontiguousarray(tris, dtype=TRI_DTYPE)
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    n = C.c_uint64(0)
+    args = (_ptr(tris), tris.shape[0], _ptr(nodes), nodes.shape[0], leaf_size, box_mode, topology, flags)
+    if lib.rt_test_scene_blob(*args, None, 0, C.byref(n)):
+        raise RtError("rt_test_scene_blob failed")
+    out = np.zeros(n.value, dtype=np.uint8)
+    if lib.rt_test_scene_blob(*args, _ptr(out), out.nbytes, C.byref(n)):
+        raise RtError("rt_test_scene_blob failed")
+    return out
+
+
+def scene_blob_info(blob: np.ndarray):
+    """Header of a scene block, or None if rt_import_scene would refuse it."""
+    lib = load_library()
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    info = np.zeros(16, dtype=np.uint64)
+    if lib.rt_test_scene_blob_info(_ptr(blob), blob.nbytes, _ptr(info)):
+        return None
+    keys = ["wide_nodes", "prims", "uv", "float_nodes", "binary_nodes", "total_bytes", "depth", "stack_entries",
+            "off_qnodes", "off_prims", "off_shade", "off_uv", "off_float_nodes", "off_binary_nodes"]
+    return {k: int(v) for k, v in zip(keys, info)}
+
+
 def write_ppm(path: str, fb: np.ndarray) -> None:
     """PPM writer of __renderScene (pbrt_engine.cu:123-133).  fb: (ny, nx, 3) float32, row 0 = bottom."""
     lib = load_library()
@@ -227,7 +259,11 @@ class PbrtEngine:
             raise RtError(f"rt_create failed ({rc}): no usable HIP device {device}; there is no CPU fallback")
         self.nx, self.ny, self.ns = nx, ny, ns
         self.tx = self.ty = 16  # printed only; the launch geometry is the library's (8x8 tiles, 64-lane waves)
+        self.m_vecScene = []    # registered meshes (addMesh, pbrt_engine.h:99-100): flattened at render time
+        self._textures = []     # (index, rgba8) registered for genTextures (pbrt_engine.h:133)
+        self.num_triangles = 0
         self.nx_ny_changed = False
+        self.rand_calls_before = 0  # rand() calls the host made before the next build (main.cpp:449-474 shares rand())
         self.last_stats = RtStats()
         self.uponPixelNumChange()
 
@@ -262,8 +298,35 @@ class PbrtEngine:
     def setNs(self, ns: int):
         self.ns = ns
 
+    def set(self, nx: int, ny: int, ns: int):
+        self.nx, self.ny, self.ns = nx, ny, ns
+
     def uponPixelNumChange(self):
         self._check(self._lib.rt_resize(self._h, self.nx, self.ny, self.ns), "rt_resize")
+
+    # -- scene registration (pbrt_engine.h:99-100,133; pbrt_engine.cu:159-178) -------------
+    def addMesh(self, m):
+        """A list replaces the scene, a single mesh is appended (the reference's two overloads).  A mesh is anything
+        with a ``name`` and ``gen_triangles()`` returning TRI_DTYPE records (rt_amd.scene_graph.Mesh)."""
+        if isinstance(m, (list, tuple)):
+            self.m_vecScene = list(m)
+        else:
+            self.m_vecScene.append(m)
+
+    def registerTexture(self, index: int, rgba8: np.ndarray):
+        self._textures.append((index, np.ascontiguousarray(rgba8, dtype=np.uint8)))
+
+    def genTextures(self):
+        """The reference builds its texture objects from image files here (cuManyTextures); the host registers decoded
+        RGBA8 images instead and this hands them to the library."""
+        for index, t in self._textures:
+            self.setTexture(index, t)
+
+    def _gather(self) -> np.ndarray:
+        """__genTrianglesFromScene, pbrt_engine.cu:167-178: the mesh named "light" first, then the others in order."""
+        parts = [m.gen_triangles() for m in self.m_vecScene if m.name == "light"]
+        parts += [m.gen_triangles() for m in self.m_vecScene if m.name != "light"]
+        return np.concatenate(parts) if parts else np.zeros(0, dtype=TRI_DTYPE)
 
     # -- scene ------------------------------------------------------------------------------
     def setTriangles(self, tris: np.ndarray):
@@ -278,6 +341,27 @@ class PbrtEngine:
     def setBvhNodes(self, nodes: np.ndarray):
         nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
         self._check(self._lib.rt_set_bvh_nodes(self._h, _ptr(nodes), int(nodes.shape[0])), "rt_set_bvh_nodes")
+
+    def exportSceneSize(self, flags: int = 0) -> int:
+        n = C.c_uint64(0)
+        self._check(self._lib.rt_export_scene(self._h, flags, None, 0, C.byref(n)), "rt_export_scene")
+        return int(n.value)
+
+    def exportScene(self, flags: int = 0, out: np.ndarray | None = None) -> np.ndarray:
+        """The built device scene as one block of bytes (rt_export_scene); `out`: a uint8 buffer to fill, e.g. a
+        np.memmap of a file in /dev/shm that the other ranks of the node map."""
+        size = self.exportSceneSize(flags)
+        if out is None:
+            out = np.zeros(size, dtype=np.uint8)
+        assert out.dtype == np.uint8 and out.nbytes >= size
+        n = C.c_uint64(0)
+        self._check(self._lib.rt_export_scene(self._h, flags, _ptr(out), out.nbytes, C.byref(n)), "rt_export_scene")
+        return out
+
+    def importScene(self, blob: np.ndarray):
+        blob = np.asarray(blob)
+        assert blob.dtype == np.uint8 and blob.flags["C_CONTIGUOUS"]
+        self._check(self._lib.rt_import_scene(self._h, C.c_void_p(blob.ctypes.data), blob.nbytes), "rt_import_scene")
 
     def getBvhNodes(self) -> np.ndarray:
         m = C.c_int(0)
@@ -363,8 +447,10 @@ class PbrtEngine:
               f"{self.tx}x{self.ty} blocks.", file=file)
         if _buildScene:
             print("INFO: generate scene.", file=file)
+            if self.m_vecScene:  # __renderScene, pbrt_engine.cu:96-98: clear, gather, build
+                self.setTriangles(self._gather())
             print(f"Total num of Triangles: {self.num_triangles}", file=file)
-            self.buildBvh()
+            self.buildBvh(self.rand_calls_before)
         else:
             print("INFO: using scene generated.", file=file)
         fb = self.render()

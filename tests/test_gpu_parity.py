@@ -353,8 +353,10 @@ def test_tile_sharding_sums_to_the_frame():
 
 
 def test_cpp_host_example(oracle, tmp_path):
-    """The C++ PbrtEngine shim (rt_amd/csrc/rt_engine.hpp) driven by examples/render_ppm.cpp, as the reference's
-    `render param nx ny ns` + `render` console commands would: its output.ppm equals the oracle's, byte for byte."""
+    """The C++ PbrtEngine shim (rt_amd/csrc/rt_engine.hpp) driven by examples/render_ppm.cpp as the reference's main()
+    drives its engine: meshes registered with addMesh (the ground before the light; the gather puts "light" first,
+    pbrt_engine.cu:167-178), genTextures, `render param nx ny ns` + `render`: its output.ppm equals the oracle's, byte
+    for byte."""
     import subprocess
 
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "render_ppm")
@@ -375,6 +377,43 @@ def test_cpp_host_example(oracle, tmp_path):
     fb, _ = oracle.render(tris, nodes, oracle.material_table(), ocam, nx, ny, ns, 50, mode=0)
     oracle.write_ppm(str(tmp_path / "ref.ppm"), fb)
     assert (tmp_path / "output.ppm").read_bytes() == (tmp_path / "ref.ppm").read_bytes()
+
+
+def test_python_engine_add_mesh_gathers_light_first(tmp_path):
+    """PbrtEngine.addMesh / genTextures of the Python mirror (pbrt_engine.h:99-100,133): meshes registered in any order
+    are flattened at render time with "light" first (pbrt_engine.cu:167-178); the frame equals the one rendered from
+    the same records passed directly."""
+    from rt_amd import scene_graph as sg
+
+    g = np.array([[-20, 0, -20], [-20, 0, 20], [20, 0, 20], [20, 0, -20]], dtype=np.float32)
+    ground = sg.Mesh("ground", g, [0, 1, 2, 0, 2, 3], mat_type=8)
+    wall = sg.plane_mesh("yz")  # names texture 0
+    wall.scale_command(6.0)
+    wall.translate_command(-3.0, 2.0, 0.0)
+    eng = rt_amd.PbrtEngine(96, 54, 4, device=0)
+    eng.addMesh(ground)
+    eng.addMesh(wall)
+    eng.addMesh(sg.light_mesh())
+    eng.registerTexture(0, sg.default_texture())
+    eng.genTextures()
+    eng.setCamera(**scenes.DEFAULT_CAMERA)
+    with open(tmp_path / "log.txt", "w") as log:
+        fb = eng.renderScene(True, str(tmp_path / "a.ppm"), file=log)
+    assert "Total num of Triangles: 6" in (tmp_path / "log.txt").read_text()
+    tris = np.concatenate([sg.light_mesh().gen_triangles(), ground.gen_triangles(), wall.gen_triangles()])
+    ref = rt_amd.PbrtEngine(96, 54, 4, device=0)
+    ref.setTriangles(tris)
+    ref.buildBvh()
+    ref.setTexture(0, sg.default_texture())
+    ref.setCamera(**scenes.DEFAULT_CAMERA)
+    assert ref.getBvhNodes().tobytes() == eng.getBvhNodes().tobytes()
+    assert ref.render().tobytes() == fb.tobytes()
+    eng.addMesh([sg.light_mesh()])  # the list form replaces the scene
+    with open(tmp_path / "log2.txt", "w") as log:
+        eng.renderScene(True, str(tmp_path / "b.ppm"), file=log)
+    assert "Total num of Triangles: 2" in (tmp_path / "log2.txt").read_text()
+    eng.close()
+    ref.close()
 
 
 def test_cpp_console_session_equals_the_python_one(oracle, tmp_path):
@@ -741,11 +780,72 @@ def test_big_scene_cfg5(oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("flags,fmt,kernel", [(0, 1, 2), (3, 0, 1), (1, 0, 0)])
+def test_export_import_scene(oracle, tmp_path, flags, fmt, kernel):
+    """rt_export_scene / rt_import_scene: a context that only imports the block another context built -- here through
+    a file mapping, as ranks of one node share it -- renders the same frame and primary hits, bit for bit, and the
+    oracle's; without the float nodes in the block the float-node kernels are refused; a layout option changed after
+    the import is an error, not a silent rebuild."""
+    tris = np.concatenate([_textured_scene(), scenes.heightfield(24)[2:]])
+    cam = dict(lookfrom=[3, 4, 11], lookat=[0, 1.5, 0], vfov=40.0, dist_to_focus=10.0, aperture=0.0)
+    nx, ny, ns, depth = 120, 68, 4, 10
+    tex0 = np.full((4, 4, 4), 200, dtype=np.uint8)
+    tex5 = np.random.default_rng(3).integers(0, 256, size=(5, 7, 4), dtype=np.uint8)
+    a = _engine(tris, nx, ny, ns, depth, cam)
+    a.setTexture(0, tex0), a.setTexture(5, tex5)
+    want = a.render()
+    want_ids, want_t = a.tracePrimary()
+    path = tmp_path / "scene.bin"
+    size = a.exportSceneSize(flags)
+    mm = np.memmap(path, dtype=np.uint8, mode="w+", shape=(size,))
+    a.exportScene(flags, out=mm)
+    mm.flush()
+    del mm
+    b = rt_amd.PbrtEngine(nx, ny, ns, device=0)
+    b.setOption(engine.OPT_NODE_FORMAT, fmt)
+    b.setOption(engine.OPT_KERNEL, kernel)
+    b.importScene(np.memmap(path, dtype=np.uint8, mode="r"))
+    b.setMaxDepth(depth)
+    b.setCamera(**cam)
+    b.setTexture(0, tex0)
+    with pytest.raises(rt_amd.RtError, match="texture 5"):
+        b.render()
+    b.setTexture(5, tex5)
+    assert b.render().tobytes() == want.tobytes()
+    assert b.last_stats.prims == tris.shape[0] and b.last_stats.wide_nodes == a.last_stats.wide_nodes
+    ids, ts = b.tracePrimary()
+    assert ids.tobytes() == want_ids.tobytes() and ts.tobytes() == want_t.tobytes()
+    if flags & 2:
+        assert b.getBvhNodes().tobytes() == a.getBvhNodes().tobytes()
+    else:
+        assert b.getBvhNodes().shape[0] == 0
+    if not flags & 1:
+        b.setOption(engine.OPT_NODE_FORMAT, 0)
+        with pytest.raises(rt_amd.RtError, match="no float nodes"):
+            b.render()
+        b.setOption(engine.OPT_NODE_FORMAT, 1)
+    oracle.set_texture(0, tex0), oracle.set_texture(5, tex5)
+    ocam = oracle.camera(cam["lookfrom"], cam["lookat"], 40.0, nx / ny, 0.0, 10.0)
+    fb_o, _ = oracle.render(tris, a.getBvhNodes(), oracle.material_table(), ocam, nx, ny, ns, depth, mode=1)
+    assert want.tobytes() == fb_o.tobytes()
+    b.setOption(engine.OPT_LEAF_SIZE, 4)
+    with pytest.raises(rt_amd.RtError, match="imported scene"):
+        b.render()
+    with pytest.raises(rt_amd.RtError, match="imported"):
+        b.exportSceneSize(0)
+    b.setTriangles(scenes.heightfield(8))  # a context can go back to building its own scene
+    b.buildBvh()
+    assert b.render().shape == (ny, nx, 3)
+    a.close()
+    b.close()
+
+
 def test_bench_two_ranks_as_typed(tmp_path):
     """`python bench.py --gpus 2 ...` as the driver types it, with no torch.distributed environment: the process starts
     its two ranks itself and relays rank 0's line.  Rehearsed on this one GPU (RT_BENCH_REHEARSE=1: both ranks on
     device 0, assembly over gloo): the line reports n_gpus, the scaling kind and that the assembled frame equals the
-    frame one context renders alone -- weak scaling (the frame grows) and --strong (config 4's fixed frame, small here)."""
+    frame one context renders alone -- weak scaling (the frame grows) and --strong (config 4's fixed frame, small here;
+    with --share-scene on: rank 0 builds, rank 1 imports the device layout from /dev/shm, as for config 5's scene)."""
     import subprocess
     import sys
 
@@ -753,7 +853,7 @@ def test_bench_two_ranks_as_typed(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["RT_BENCH_REHEARSE"] = "1"
     for extra, scaling, frame in ((["--nx", "320", "--ny", "180", "--spp", "4"], "weak", "453x255"),
-                                  (["--strong", "--nx", "384", "--ny", "216", "--spp", "6"], "strong", "384x216")):
+                                  (["--strong", "--nx", "384", "--ny", "216", "--spp", "6", "--share-scene", "on"], "strong", "384x216")):
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                               "--grid", "64", "--no-cpu-baseline"] + extra, env=env, cwd=tmp_path, capture_output=True,
                              text=True, timeout=280)
@@ -763,6 +863,7 @@ def test_bench_two_ranks_as_typed(tmp_path):
         line = json.loads(lines[0])
         assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["config"]["frame"] == frame
         assert line["assembled_frame_equals_single_gpu_frame"] is True
+        assert line["config"]["scene_shared_from_rank0"] is ("--share-scene" in extra)  # rank 1 imported rank 0's build
         assert line["value"] > 0 and line["steps"] == 2
 
 

@@ -335,3 +335,47 @@ def test_null_context_is_an_error_not_a_crash():
     assert lib.rt_write_ppm(None, buf, 1, 1) != 0
     with pytest.raises(engine.RtError, match="no usable HIP device"):
         engine.PbrtEngine(8, 8, 1)
+
+
+@pytest.mark.parametrize("flags", [0, 1, 2, 3])
+def test_scene_blob_round_trip(flags):
+    """rt_export_scene's block (here from the no-GPU hook): its sections are, byte for byte, the arrays of the device
+    layout built from the same records and nodes; the header says what is in it; truncated or altered blocks are what
+    rt_import_scene refuses."""
+    tris = np.concatenate([scenes.heightfield(20), scenes.make_spheres(np.array([[0, 2, 0]], np.float32), [1.0], 7)])
+    nodes = engine.host_build_bvh(tris)
+    blob = engine.host_scene_blob(tris, nodes, leaf_size=2, box_mode=0, topology=3, flags=flags)
+    info = engine.scene_blob_info(blob)
+    assert info is not None and info["total_bytes"] == blob.nbytes and blob.nbytes % 256 == 0
+    wide, qn, prims, depth, stack = engine.host_wide_layout(tris, nodes, leaf_size=2, box_mode=0, quant=True, topology=3)
+    assert info["wide_nodes"] == qn.shape[0] and info["prims"] == prims.shape[0] == tris.shape[0]
+    assert info["depth"] == depth and info["stack_entries"] == stack and info["uv"] == 0
+    assert info["float_nodes"] == (wide.shape[0] if flags & 1 else 0)
+    assert info["binary_nodes"] == (nodes.shape[0] if flags & 2 else 0)
+    sec = lambda off, arr: blob[off:off + arr.nbytes].tobytes() == arr.tobytes()  # noqa: E731
+    assert sec(info["off_qnodes"], qn) and sec(info["off_prims"], prims)
+    if flags & 1:
+        assert sec(info["off_float_nodes"], wide)
+    if flags & 2:
+        assert sec(info["off_binary_nodes"], nodes)
+    for off in ("off_qnodes", "off_prims", "off_shade", "off_uv", "off_float_nodes", "off_binary_nodes"):
+        assert info[off] % 256 == 0
+    # what an importer refuses: a short block, a wrong magic, a header that promises more than the block holds
+    assert engine.scene_blob_info(blob[:-256]) is None
+    assert engine.scene_blob_info(blob[:100]) is None
+    bad = blob.copy()
+    bad[0] ^= 0xFF
+    assert engine.scene_blob_info(bad) is None
+    bad = blob.copy()
+    bad[8:16] = np.frombuffer(np.uint64(info["wide_nodes"] + 4).tobytes(), dtype=np.uint8)  # +256 bytes of nodes
+    assert engine.scene_blob_info(bad) is None
+
+
+def test_scene_blob_carries_texture_coordinates():
+    tris = scenes.heightfield(6).copy()
+    tris["texIdx"][5] = 3
+    tris["u"][5] = [0.0, 1.0, 0.0]
+    tris["v"][5] = [0.0, 0.0, 1.0]
+    nodes = engine.host_build_bvh(tris)
+    info = engine.scene_blob_info(engine.host_scene_blob(tris, nodes))
+    assert info["uv"] == info["prims"] == tris.shape[0]
