@@ -403,22 +403,24 @@ def main():
         else:
             roof.update({"bound": "vector_l1", "achieved": None, "peak": L1_PEAK_GBS, "unit": "GB/s", "frac": None,
                          "note": "no committed counter pass for this workload / rank count: see profiles/"})
-        # memory side, secondary: bytes the DEVICE tree makes a ray touch (64-B quantized node per visit, 48-B primitive
-        # per test, 28 B ray in + 8 B hit out), against HBM peak; and the L2s' fabric traffic from the counter passes
-        mem = {"peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        # memory side, for reference (no fraction is claimed for HBM: at this scene size the caches serve nearly all of
+        # it): bytes the DEVICE tree makes a ray touch (64-B quantized node per visit, 48-B primitive per test, 28 B ray
+        # in + 8 B hit out; counts from the analysis build), the L2s' fabric traffic from the counter passes, and SURVEY
+        # 8d's figure for an ordered traversal of the reference's BINARY tree, counted live by the oracle on the CPU sample
+        mem = {"hbm_peak": HBM_PEAK_GBS, "unit": "GB/s"}
         if "node_visits_per_ray" in prof:
             dev_bytes = 64.0 * prof["node_visits_per_ray"] + 48.0 * prof["prim_tests_per_ray"] + 36.0
-            mem.update({"device_bytes_per_ray": dev_bytes, "achieved": dev_bytes * rays_per_launch / kernel_s / 1e9,
-                        "frac": dev_bytes * rays_per_launch / kernel_s / 1e9 / HBM_PEAK_GBS})
+            mem.update({"device_bytes_per_ray": dev_bytes, "device_bytes_rate_gbs": dev_bytes * rays_per_launch / kernel_s / 1e9,
+                        "node_visits_per_ray": prof["node_visits_per_ray"], "prim_tests_per_ray": prof["prim_tests_per_ray"]})
         if same_workload and "fabric_bytes_per_launch" in prof:
             mem["fabric_traffic_bytes_per_launch"] = prof["fabric_bytes_per_launch"]
             mem["fabric_traffic_gbs"] = prof["fabric_bytes_per_launch"] / kernel_s / 1e9
+            mem["fabric_traffic_share_of_hbm_peak"] = mem["fabric_traffic_gbs"] / HBM_PEAK_GBS
             mem["fabric_traffic_note"] = "L2-side fabric requests, Infinity-Cache hits included: an upper bound on HBM bytes"
         if bytes_per_ray is not None:
-            # SURVEY 8d's figure: an ordered t-shrinking traversal of the reference's BINARY tree, counted live by the
-            # oracle on the CPU sample.  Kept for reference: it does not describe this kernel (its frac passes 1).
             mem["algorithmic_bytes_per_ray_binary_tree"] = bytes_per_ray
-            mem["binary_tree_frac"] = bytes_per_ray * rays_per_launch / kernel_s / 1e9 / HBM_PEAK_GBS
+            mem["binary_tree_rate_gbs"] = bytes_per_ray * rays_per_launch / kernel_s / 1e9
+            mem["binary_tree_note"] = "SURVEY 8d's model; it does not describe this kernel (16 visits of 64-B wide nodes per ray, not 571 box tests)"
         roof["hbm"] = mem
         roof["traffic"] = mem.get("fabric_traffic_bytes_per_launch")
         line = {
