@@ -391,7 +391,9 @@ def main():
             if "l1_accesses_per_launch" in prof:
                 a = prof["l1_accesses_per_launch"] * 64.0 / kernel_s / 1e9
                 l1 = {"achieved": a, "peak": L1_PEAK_GBS, "unit": "GB/s", "frac": a / L1_PEAK_GBS,
-                      "basis": "TCP_TOTAL_CACHE_ACCESSES x 64 B per launch / kernel time; 256 CUs x 64 B per cycle x 2.4 GHz",
+                      "basis": "TCP_TOTAL_CACHE_ACCESSES x 64 B per launch / kernel time; peak = one L1 line access per cycle and CU x 256 CUs "
+                               "x 2.4 GHz, the ceiling tools/micro/l1_rate.hip measures (0.99 lane-loads per cycle and CU when every "
+                               "lane reads a 128-byte line of its own: profiles/r02_l1_rate.jsonl)",
                       "accesses_per_cycle_per_cu_at_measured_clock": prof.get("l1_accesses_per_cycle_per_cu"),
                       "td_busy_frac": prof.get("td_busy_frac"), "ta_busy_frac": prof.get("ta_busy_frac"),
                       "l1_hit_rate": prof.get("l1_hit_rate"), "l2_hit_rate": prof.get("l2_hit_rate")}
