@@ -123,7 +123,7 @@ struct Sim {
             wn[wk.w] = w;
         }
     }
-    struct Counts { double rays = 0, visits = 0, box = 0, prim = 0, hits = 0; };
+    struct Counts { double rays = 0, visits = 0, box = 0, prim = 0, hits = 0, cullable = 0, nohit = 0; };
     bool tri_hit(int32_t prim, V3 o, V3 d, float tmax, float &t) const {
         const rt_triangle148 &T = tris[prim];
         if (T.shapeType != 0) return false;
@@ -146,14 +146,17 @@ struct Sim {
         int best = -1;
         tbest = 3.0e38f;
         int32_t stack[256];
+        float stack_tn[256]; // entry distance of the pushed child: a visit whose entry lies beyond the best hit is wasted
         int sp = 0;
-        stack[sp++] = 0;
+        stack_tn[sp] = 0.0f, stack[sp++] = 0;
         c.rays++;
         while (sp) {
-            int32_t cur = stack[--sp];
+            --sp;
+            int32_t cur = stack[sp];
             if (cur < 0) continue;
             const WNode &w = wn[cur];
             c.visits++;
+            if (stack_tn[sp] > tbest) c.cullable++;
             c.box += W; // the kernel tests every slot of a node, empty or not
             struct Hitc { float tn; int s; } hc[8];
             int nh = 0;
@@ -166,10 +169,11 @@ struct Sim {
                 }
                 if (tn <= tf) hc[nh++] = {tn, s};
             }
+            if (nh == 0) c.nohit++;
             std::sort(hc, hc + nh, [](const Hitc &a, const Hitc &b) { return a.tn > b.tn; }); // far first onto the stack
             for (int k = 0; k < nh; k++) {
                 int s = hc[k].s;
-                if (w.child[s] >= 0) stack[sp++] = w.child[s];
+                if (w.child[s] >= 0) stack_tn[sp] = hc[k].tn, stack[sp++] = w.child[s];
                 else { // leaves are tested where they are met (the kernel postpones them; same counts)
                     for (int i = 0; i < w.cnt[s]; i++) {
                         float t;
@@ -229,9 +233,9 @@ int main(int argc, char **argv) {
             const char *names[3] = {"camera", "bounce 1", "bounce 2"};
             for (int b = 0; b < 3; b++)
                 std::printf("{\"width\": %d, \"leaf_size\": %d, \"wide_nodes\": %zu, \"rays\": \"%s\", \"n\": %.0f, \"hit_share\": %.3f, "
-                            "\"node_visits_per_ray\": %.2f, \"box_tests_per_ray\": %.1f, \"prim_tests_per_ray\": %.2f}\n",
+                            "\"node_visits_per_ray\": %.2f, \"box_tests_per_ray\": %.1f, \"prim_tests_per_ray\": %.2f, \"visits_entered_beyond_best_hit\": %.3f, \"visits_hitting_no_child\": %.3f}\n",
                             W, leaf, S.wn.size(), names[b], c[b].rays, c[b].hits / c[b].rays, c[b].visits / c[b].rays, c[b].box / c[b].rays,
-                            c[b].prim / c[b].rays);
+                            c[b].prim / c[b].rays, c[b].cullable / c[b].visits, c[b].nohit / c[b].visits);
         }
     return 0;
 }
