@@ -1140,6 +1140,16 @@ struct PersistArgs {
 // OCC: waves per SIMD the register allocation is held to (__launch_bounds__' second argument).
 // (7 waves per SIMD, 72 VGPRs, 28 waves per CU on a 12-entry LDS stack: 34 spilled registers, none in the node step,
 // and 45.8 ms against 45.7 for 6 -- the seventh wave buys what its spills cost.)
+struct KArgs { // k_persistent's arguments as they lie in the kernel-argument segment
+    KernelScene S;
+    KernelFrame F;
+    PersistArgs P;
+    float *fb;
+    int32_t *ids;
+    float *ts;
+};
+typedef __attribute__((address_space(4))) const KArgs CKArgs;
+
 template <int MODE, int FMT, int SPEC, int OCC, bool TEX>
 __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFrame F, PersistArgs P, float *fb, int32_t *ids,
                                                    float *ts) {
@@ -1147,7 +1157,6 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
     StackRef K;
     stack_ref_init(K, lane, P.spill, P.lds_entries, P.total_lanes);
     const uint32_t home = xcc_id();
-    const uint32_t n_tiles = (uint32_t)F.n_local_tiles;
     SlotQueue q;
     q.next = q.end = q.empty = q.round = q.base_slot = 0u;
     q.band_slots = 1u;
@@ -1186,6 +1195,17 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
         const unsigned long long clk0 = __builtin_readcyclecounter();
 #endif
         since_poll = 0;
+        // refill-only launch data comes from the kernel-argument segment afresh every time (scalar loads that are dead
+        // again when the phase ends) instead of living in scalar registers across the traversal loop
+        CKArgs *A = (CKArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(A));
+        const KernelFrame &RF = *(const KernelFrame *)&A->F;
+        const KernelScene &RS = *(const KernelScene *)&A->S;
+        const PersistArgs &RP = *(const PersistArgs *)&A->P;
+        float *const r_fb = A->fb;
+        int32_t *const r_ids = A->ids;
+        float *const r_ts = A->ts;
+        const uint32_t n_tiles = (uint32_t)RF.n_local_tiles;
         bool want_push = false;
         RT_STAT(kStatShadeLanes, __popcll(ballot(has_pixel && result_ready)));
         if (has_pixel && result_ready) {
@@ -1193,33 +1213,33 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
             Hit h;
             h.t = T.best_t;
             h.rank = T.best_rank;
-            const size_t pixel_index = (size_t)(pij >> 16) * (size_t)F.nx + (size_t)(pij & 0xFFFFu);
+            const size_t pixel_index = (size_t)(pij >> 16) * (size_t)RF.nx + (size_t)(pij & 0xFFFFu);
             if (MODE == 1) {
                 if (h.rank != RT_NO_HIT) {
-                    ids[pixel_index] = __float_as_int(S.prims[3 * (size_t)h.rank + 2].z);
-                    ts[pixel_index] = h.t;
+                    r_ids[pixel_index] = __float_as_int(RS.prims[3 * (size_t)h.rank + 2].z);
+                    r_ts[pixel_index] = h.t;
                 } else {
-                    ids[pixel_index] = -1;
-                    ts[pixel_index] = 0.0f;
+                    r_ids[pixel_index] = -1;
+                    r_ts[pixel_index] = 0.0f;
                 }
                 has_pixel = false;
             } else {
                 bool clamp;
-                bool go_on = shade_bounce<TEX>(S, h, cur, thr, g, clamp);
+                bool go_on = shade_bounce<TEX>(RS, h, cur, thr, g, clamp);
                 bounce++;
-                if (!go_on || bounce >= F.max_depth) {
+                if (!go_on || bounce >= RF.max_depth) {
                     if (clamp) clip_color(thr);
                     col = vadd(col, thr);
                     k++;
-                    if (k == F.ns) {
-                        if (!F.raw_sum) {
-                            float kk = (float)(1.0 / (double)(float)F.ns);
+                    if (k == RF.ns) {
+                        if (!RF.raw_sum) {
+                            float kk = (float)(1.0 / (double)(float)RF.ns);
                             col = mk(col.x * kk, col.y * kk, col.z * kk);
                             clip_color(col);
                         }
-                        fb[3 * pixel_index + 0] = col.x;
-                        fb[3 * pixel_index + 1] = col.y;
-                        fb[3 * pixel_index + 2] = col.z;
+                        r_fb[3 * pixel_index + 0] = col.x;
+                        r_fb[3 * pixel_index + 1] = col.y;
+                        r_fb[3 * pixel_index + 2] = col.z;
                         has_pixel = false;
                     } else if (ring_on && k == yield_k) {
                         want_push = true;
@@ -1234,7 +1254,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
         RT_STAT(kStatShadeClocks, clk_shade - clk0);
 #endif
         if (ring_on && want_push) { // end of this round's share: publish the state under the next round's tag
-            ring_publish(P.round_state, P.round_bytes, slot_round & 0x3FFFFFFu, P.frame_id * 64u + (slot_round >> 26) + 1u, g.v0, g.v1,
+            ring_publish(RP.round_state, RP.round_bytes, slot_round & 0x3FFFFFFu, RP.frame_id * 64u + (slot_round >> 26) + 1u, g.v0, g.v1,
                          g.v2, g.v3, g.v4, g.d, col, k);
             has_pixel = false;
         }
@@ -1247,7 +1267,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
             const bool need = !has_pixel && !retired && !waiting;
             RT_STAT(kStatFetchLanes, __popcll(ballot(need)));
             uint32_t round = 0;
-            const bool got = fetch_slot(P.chunk, P.band_counters, n_tiles, home, q, need, slot, rounds, round);
+            const bool got = fetch_slot(RP.chunk, RP.band_counters, n_tiles, home, q, need, slot, rounds, round);
 #ifdef RT_TRAV_STATS
             if (q.empty == 0xFFu && wave_t_dry == 0) wave_t_dry = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1256,17 +1276,17 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                     retired = true;
                 } else {
                     const uint32_t local = slot >> 6, within = slot & 63u;
-                    const uint32_t gt = local * (uint32_t)F.shard_world + (uint32_t)F.shard_rank;
+                    const uint32_t gt = local * (uint32_t)RF.shard_world + (uint32_t)RF.shard_rank;
                     int tx, ty;
                     tile_xy(F, gt, tx, ty);
                     const int pi = tx * 8 + (int)(within & 7u), pj = ty * 8 + (int)(within >> 3);
-                    if (pi < F.nx && pj < F.ny) { // ragged edge tiles: the slot is simply dropped, in every round
+                    if (pi < RF.nx && pj < RF.ny) { // ragged edge tiles: the slot is simply dropped, in every round
                         pij = ((uint32_t)pj << 16) | (uint32_t)pi;
                         slot_round = slot | (round << 26);
                         // this round runs samples up to (round + 1) * ns / rounds; the last round ends at ns
-                        yield_k = P.round_end[round];
+                        yield_k = RP.round_end[round];
                         if (round == 0u) {
-                            rng_init(g, (uint64_t)(1995 + pj * F.nx + pi) + F.seed_salt);
+                            rng_init(g, (uint64_t)(1995 + pj * RF.nx + pi) + RF.seed_salt);
                             col = mk(0, 0, 0);
                             k = 0;
                             has_pixel = true;
@@ -1279,7 +1299,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
             }
             if (ring_on && waiting) { // has the previous round's lane published it yet?
                 uint32_t w[10];
-                if (ring_poll(P.round_state, P.round_bytes, slot_round & 0x3FFFFFFu, P.frame_id * 64u + (slot_round >> 26), w)) {
+                if (ring_poll(RP.round_state, RP.round_bytes, slot_round & 0x3FFFFFFu, RP.frame_id * 64u + (slot_round >> 26), w)) {
                     g.v0 = w[0], g.v1 = w[1], g.v2 = w[2], g.v3 = w[3], g.v4 = w[4], g.d = w[5];
                     col = mk(__uint_as_float(w[6]), __uint_as_float(w[7]), __uint_as_float(w[8]));
                     k = (int)w[9];
@@ -1297,7 +1317,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
         RT_STAT(kStatPrimaryLanes, __popcll(ballot(has_pixel && !tracing && need_primary)));
         if (has_pixel && !tracing) {
             if (need_primary) {
-                cur = primary_ray(F.cam, (int)(pij & 0xFFFFu), (int)(pij >> 16), F.nx, F.ny, g);
+                cur = primary_ray(RF.cam, (int)(pij & 0xFFFFu), (int)(pij >> 16), RF.nx, RF.ny, g);
                 thr = mk(1.0f, 1.0f, 1.0f);
                 bounce = 0;
                 need_primary = false;
@@ -1319,8 +1339,8 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
         if (live_m == 0ull) break;
         // The refill threshold is a share of the lanes that still have work: at the end of a frame retired lanes pile
         // up, and a fixed count would send the wave through the whole refill phase for every single ray that ends.
-        const int thr_eff = (P.threshold * (int)__popcll(live_m) + 63) >> 6;
-        const int batch_eff = (P.leaf_batch * (int)__popcll(live_m) + 63) >> 6; // the leaf batch likewise
+        const int thr_eff = (RP.threshold * (int)__popcll(live_m) + 63) >> 6;
+        const int batch_eff = (RP.leaf_batch * (int)__popcll(live_m) + 63) >> 6; // the leaf batch likewise
         if (ring_on && ballot(tracing) == 0ull) {
             // every live lane waits for a ring item: nothing to do but poll.  Sleep between polls (127 x 64 clocks,
             // ~3.5 us) so that the waiting wave leaves the SIMD's issue slots to the waves that still produce.
