@@ -90,6 +90,10 @@ __device__ __forceinline__ PrimRegs prim_load(const float4 *__restrict__ prims, 
     const float4 *p = prims + 3 * (size_t)rank;
     PrimRegs R;
     R.A = p[0], R.B = p[1], R.C = p[2];
+    // The test reads C.x, C.y and C.w, and hipcc narrows the third load to a dwordx2 plus a dword: FOUR vector-memory
+    // instructions per primitive, each one L1 access per lane, where three fetch the record.  Naming all of C keeps
+    // it one dwordx4.
+    asm volatile("" ::"v"(R.C.x), "v"(R.C.y), "v"(R.C.z), "v"(R.C.w));
     return R;
 }
 __device__ __forceinline__ bool prim_test(const PrimRegs &R, const Ray &r, float &t_out, int &ref_rank) {
