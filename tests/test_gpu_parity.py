@@ -914,3 +914,12 @@ def test_console_session_default_scene(oracle, tmp_path):
     assert "INFO: using scene generated." in out and "Console Error" not in out
     check(calls + sg.build_rand_calls(689))
     eng.close()
+
+
+def test_driver_smoke_entry(capsys):
+    """__graft_entry__.smoke() -- what the driver runs before the bench: one small frame and its primary hits, checked
+    against the oracle inside the function (it raises on any difference)."""
+    import __graft_entry__ as entry
+
+    entry.smoke()
+    assert "smoke ok" in capsys.readouterr().out
