@@ -386,6 +386,16 @@ def main():
                     "lane_utilisation": prof.get("lane_utilisation"),
                     "useful_lane_frac": achieved / peak * prof.get("lane_utilisation", 0.0),
                     "waves_per_simd": prof.get("waves_per_simd")}
+            # against what a SIMD was MEASURED to issue (tools/micro/valu_rate.hip, 8 waves per SIMD): independent
+            # v_fma_f32, and the node test's own instruction mix -- the practical ceilings under the 2-cycle spec
+            try:
+                for line in open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_valu_issue_rate.jsonl")):
+                    t = json.loads(line)
+                    if t.get("waves_per_simd") == 8 and t.get("kind") in ("v_fma_f32", "node-test mix"):
+                        key = "frac_of_measured_fma_rate" if t["kind"] == "v_fma_f32" else "frac_of_measured_node_mix_rate"
+                        valu[key] = achieved / (SIMDS * PEAK_CLOCK_HZ / t["cycles_per_wave64_inst"] / 1e9)
+            except Exception:  # noqa: BLE001
+                pass
             roof["valu_issue"] = valu
             l1 = None
             if "l1_accesses_per_launch" in prof:
