@@ -30,13 +30,32 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def cpu_model():
+    """The host CPU as the box names it.  Where the hypervisor masks the part number ("AMD EPYC" and no more) the
+    family / model / stepping numbers and the cache size that /proc/cpuinfo still shows are appended."""
+    info = {}
     try:
         for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
+            if ":" in line:
+                k, v = line.split(":", 1)
+                k = k.strip()
+                if k in ("model name", "cpu family", "model", "stepping", "cache size") and k not in info:
+                    info[k] = v.strip()
+            elif info:
+                break  # end of the first processor's block
     except OSError:
-        pass
-    return "unknown"
+        return "unknown"
+    name = info.get("model name", "unknown")
+    if not any(ch.isdigit() for ch in name):
+        name += " (part number masked by the host; family {} model {} stepping {}, cache {})".format(
+            info.get("cpu family", "?"), info.get("model", "?"), info.get("stepping", "?"), info.get("cache size", "?"))
+    return name
+
+
+def usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
 
 
 def cpu_baseline_and_bytes(tris, nodes, cam_args, nx, ny, ns, depth, stride, threads):
@@ -67,7 +86,10 @@ def cpu_baseline_and_bytes(tris, nodes, cam_args, nx, ny, ns, depth, stride, thr
     base = {
         "value": c_ref.rays / (t2 - t1) / 1e6,
         "unit": "Mrays/s",
-        "cores": threads,
+        "cores": threads,  # the threads the timed sample ran on (the GPU box grants one command 16 cores' worth)
+        "threads": threads,
+        "box_cores": os.cpu_count(),          # logical CPUs of the whole machine
+        "usable_cores": usable_cores(),       # CPUs this process may run on
         "kind": "port",
         "sample": f"every {stride}th pixel of every {stride}th row of the same {nx}x{ny} frame at {ns} spp, depth {depth} "
                   f"({c_ref.rays} rays), reference visit pattern ({c_ref.box_tests / c_ref.rays:.0f} box + "
@@ -199,6 +221,8 @@ def main():
     rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: local rank {local_rank} but this node shows {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -207,20 +231,22 @@ def main():
         if rehearse:
             dist.init_process_group(backend="gloo")
         else:
+            n_dev = torch.cuda.device_count()
+            if n_dev < world or local_rank >= n_dev:
+                raise SystemExit(f"bench.py --gpus {world}: this node shows {n_dev} GPU(s); one process per GPU needs {world} "
+                                 f"(local rank {local_rank}).  RT_BENCH_REHEARSE=1 rehearses the plumbing on one GPU over gloo.")
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import rt_amd
     from rt_amd import engine as E
-    from rt_amd import scenes
+    from rt_amd import scenes, sharding
 
     base_nx = args.nx or (3840 if args.strong else 1920)
     base_ny = args.ny or (2160 if args.strong else 1080)
     spp = args.spp or (1024 if args.strong else 64)
     sample_shard = args.sample_shard and world > 1
     fixed_frame = args.strong or sample_shard
-    # weak scaling (the default): pixels grow with N at fixed aspect
-    s = 1.0 if fixed_frame else math.sqrt(world)
-    nx, ny = int(round(base_nx * s)), int(round(base_ny * s))
+    nx, ny = sharding.frame_size(base_nx, base_ny, world, fixed_frame)  # weak scaling: pixels grow with N at fixed aspect
     n_tris = 2 * args.grid * args.grid + 2
     share = world > 1 and (args.share_scene == "on" or (args.share_scene == "auto" and n_tris > 4_000_000))
     ns_local, salt = E.sample_shard(rank, world, spp) if sample_shard else (spp, 0)
@@ -246,24 +272,8 @@ def main():
         # rank), the others upload straight from the mapping.  BASELINE config 5 (100 M triangles) would otherwise cost
         # every rank 14.8 GB of records, a 47 s all-core build and ~100 GB of host memory.
         path = f"/dev/shm/rt_amd_scene_{os.environ.get('MASTER_PORT', '0')}_{args.grid}.bin"
-        size = torch.zeros(1, dtype=torch.int64)
-        if rank == 0:
-            size[0] = eng.exportSceneSize(0)
-            mm = np.memmap(path, dtype=np.uint8, mode="w+", shape=(int(size[0]),))
-            eng.exportScene(0, out=mm)
-            mm.flush()
-            del mm
-        if rehearse:
-            dist.broadcast(size, src=0)
-        else:
-            size = size.to(f"cuda:{local_rank}")
-            dist.broadcast(size, src=0)  # doubles as the barrier: the file is complete when rank 0 gets here
-            size = size.cpu()
-        if rank != 0:
-            eng.importScene(np.memmap(path, dtype=np.uint8, mode="r", shape=(int(size[0]),)))
-        dist.barrier()
-        if rank == 0:
-            os.unlink(path)
+        sharding.share_through_file(dist, rank, path, lambda: eng.exportSceneSize(0), lambda mm: eng.exportScene(0, out=mm),
+                                    eng.importScene, size_device="cpu" if rehearse else f"cuda:{local_rank}")
     build_s = time.perf_counter() - t0
     eng.setMaxDepth(args.depth)
     eng.setCamera(**scenes.BENCH_CAMERA)
@@ -271,71 +281,22 @@ def main():
         eng.setShard(rank, world)
     kk = float(np.float32(1.0 / float(np.float32(spp))))
     # Two frame buffers: frame k is assembled on rank 0 (RCCL's stream) while frame k + 1 renders (the library's
-    # stream), so the exchange costs the job one reduce at the end, not one per frame.
+    # stream), so the exchange costs the job one reduce at the end, not one per frame (rt_amd/sharding.py, which
+    # tests/test_sharding_gloo.py runs over gloo with 2 and 4 ranks).
     fbs = [torch.zeros((ny, nx, 3), dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(2 if world > 1 else 1)]
-    pending = [None, None]
-    frame_no = [0]
 
-    def finish(slot):
-        """Frame assembly of the buffer in `slot` has completed (host-side): the buffer may be rendered into again."""
-        if pending[slot] is not None:
-            pending[slot].wait()
-            torch.cuda.current_stream().synchronize()
-            pending[slot] = None
-
-    def step():
-        slot = frame_no[0] % len(fbs)
-        frame_no[0] += 1
-        fb = fbs[slot]
-        finish(slot)  # the reduce of two frames ago; the library memsets and renders on its own stream
+    def render(fb):
         st = eng.renderDevice(fb.data_ptr())  # returns when the frame is in fb
-        if world > 1:
-            # frame assembly on rank 0 (the host that writes the PPM): x + 0 is exact (tiles) / sums of clamped samples
-            # (sample shards).  A reduce moves half the bytes of an all-reduce over the xGMI ring.
-            if sample_shard:
-                dist.reduce(fb, dst=0)
-                if rank == 0:
-                    fb.mul_(kk).clamp_(max=1.0)
-                torch.cuda.synchronize()
-            else:
-                pending[slot] = dist.reduce(fb, dst=0, async_op=True)
         return st.rays, st.kernel_ms
 
-    def drain():
-        for slot in range(len(fbs)):
-            finish(slot)
-
-    for _ in range(args.warmup):
-        step()
-    drain()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    rays_local, kernel_ms = 0, []
-    for _ in range(args.steps):
-        r, k = step()
-        rays_local += r
-        kernel_ms.append(k)
-    drain()  # every frame of the timed region is assembled on rank 0 before the clock stops
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    fb = fbs[(frame_no[0] - 1) % len(fbs)]  # the last frame
-
-    if world > 1:
-        small = "cpu" if rehearse else fb.device
-        t = torch.tensor([elapsed], dtype=torch.float64, device=small)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        rr = torch.tensor([rays_local], dtype=torch.int64, device=small)
-        dist.all_reduce(rr)
-        rays_total = int(rr.item())
-    else:
-        rays_total = rays_local
+    loop = sharding.FrameLoop(dist, world, rank, fbs, render, torch.cuda.synchronize, sample_shard=sample_shard,
+                              finish_sample_shards=lambda fb: fb.mul_(kk).clamp_(max=1.0))
+    elapsed, rays_local, kernel_ms = loop.run(args.warmup, args.steps)
+    fb = loop.last_frame()
+    elapsed, rays_total = sharding.job_totals(dist, world, elapsed, rays_local, "cpu" if rehearse else fb.device)
 
     assembled_ok = None
+    failed = None
     if world > 1 and rank == 0 and not sample_shard and not args.no_verify:
         whole = torch.zeros_like(fb)  # untimed: rank 0 renders the whole frame alone
         eng.setShard(0, 1)
@@ -358,18 +319,20 @@ def main():
                 "frame": f"{base_nx}x{base_ny}x1"}
         cpu, bytes_per_ray, lattice_parity = None, None, None
         if frame_cpu is not None:
-            threads = max(1, min(16, os.cpu_count() or 1))
-            # the CPU leg runs at most 64 spp of the frame's pixels (a bounded sample of the same workload); the
-            # frame the GPU was timed on is compared with the oracle's only when that IS the frame's sample count
-            cpu_spp = min(spp, 64)
-            st_ = args.cpu_stride * (2 if nx * ny > 1920 * 1080 else 1)  # the same ~32 400 pixels on a 4K frame
-            cpu, bytes_per_ray, lat_img = cpu_baseline_and_bytes(tris, eng.getBvhNodes(), scenes.BENCH_CAMERA, nx, ny, cpu_spp,
+            threads = max(1, min(16, usable_cores()))
+            # The CPU leg is a bounded sample of the SAME workload -- the frame's own sample count on a pixel lattice --
+            # so that the frame the GPU was timed on can be compared with the oracle's image on that lattice.  The
+            # lattice is thinned to keep the sample at about 32 400 pixels x 64 spp worth of paths: every 8th pixel at
+            # 1080p x 64 spp, every 16th at 2160p x 64 spp, every 64th at 2160p x 1024 spp (config 4: 2 040 pixels).
+            st_ = args.cpu_stride * (2 if nx * ny > 1920 * 1080 else 1)
+            st_ = int(round(st_ * math.sqrt(max(spp, 64) / 64.0)))
+            cpu, bytes_per_ray, lat_img = cpu_baseline_and_bytes(tris, eng.getBvhNodes(), scenes.BENCH_CAMERA, nx, ny, spp,
                                                                  args.depth, st_, threads)
-            if cpu_spp == spp:
-                lattice_parity = bool(frame_cpu[st_ // 2::st_, st_ // 2::st_].tobytes() == lat_img.tobytes())
+            lattice_parity = bool(frame_cpu[st_ // 2::st_, st_ // 2::st_].tobytes() == lat_img.tobytes())
         workload_key = f"g{args.grid}_{nx}x{ny}x{spp}_d{args.depth}"
         prof = committed_profile(workload_key)
-        same_workload = prof.get("workload") == workload_key and world == 1
+        # a counter pass taken from other sources than the ones that ran says nothing about this run: no fraction then
+        same_workload = prof.get("workload") == workload_key and world == 1 and not prof.get("profile_stale", True)
         roof = {"kernel": "k_persistent<0,1,1,6,false> (render: quantized 4-wide nodes, speculative traversal, rounds)",
                 "kernel_ms": kernel_s * 1e3, "rays_per_launch": rays_per_launch,
                 "committed_profile": prof}
@@ -414,7 +377,9 @@ def main():
                 roof.update({"bound": "valu_issue", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"], "frac": valu["frac"]})
         else:
             roof.update({"bound": "vector_l1", "achieved": None, "peak": L1_PEAK_GBS, "unit": "GB/s", "frac": None,
-                         "note": "no committed counter pass for this workload / rank count: see profiles/"})
+                         "profile_stale": bool(prof.get("profile_stale", True)),
+                         "note": "no committed counter pass of these sources for this workload / rank count (profile_stale: the "
+                                 "kernel sources changed since the pass in profiles/ was taken): no fraction is claimed"})
         # memory side, for reference (no fraction is claimed for HBM: at this scene size the caches serve nearly all of
         # it): bytes the DEVICE tree makes a ray touch (64-B quantized node per visit, 48-B primitive per test, 28 B ray
         # in + 8 B hit out; counts from the analysis build), the L2s' fabric traffic from the counter passes, and SURVEY
@@ -464,9 +429,18 @@ def main():
         if assembled_ok is not None:
             line["assembled_frame_equals_single_gpu_frame"] = assembled_ok
         print(json.dumps(line), flush=True)
+        # a frame that differs from the oracle's, or an assembled frame that differs from the single-GPU frame, is a
+        # failed run whatever its rate: the line is printed for the record and the process exits non-zero
+        if lattice_parity is False:
+            failed = "the timed frame differs from the oracle's image on the lattice (lattice_parity false)"
+        elif assembled_ok is False:
+            failed = "the frame assembled from the ranks' tiles differs from the frame one GPU renders alone"
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        print("bench.py: PARITY FAILURE: " + failed, file=sys.stderr, flush=True)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

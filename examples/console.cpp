@@ -123,8 +123,9 @@ int main(int argc, char **argv) {
                     engine.setNx(hd ? 1280 : std::stoi(tokens.at(2)));
                     engine.setNy(hd ? 720 : std::stoi(tokens.at(3)));
                     engine.setNs(hd ? 100 : std::stoi(tokens.at(4)));
-                    if (engine.nXnYChanged()) engine.uponPixelNumChange();
-                    else engine.uponPixelNumChange(); // ns reaches the library through rt_resize as well
+                    // the reference resizes only when nx or ny changed (main.cpp:199-201); here ns reaches the library
+                    // through rt_resize as well, so every `render param` resizes
+                    engine.uponPixelNumChange();
                 } else {
                     const bool build = !(tokens.size() >= 2 && tokens[1] == "-cache");
                     if (build) { // main.cpp:711-713 registers every mesh of the name-sorted collection with the engine

@@ -112,7 +112,9 @@ int rt_get_bvh_nodes(rt_ctx *ctx, rt_bvh_node32 *out, int cap, int *m);
  * rt_export_scene: out == NULL returns the size in *bytes; flags bit 0 = include the 128-byte float nodes
  * (RT_OPT_NODE_FORMAT 0 / RT_OPT_KERNEL 0 need them), bit 1 = include the reference's binary node array (so that
  * rt_get_bvh_nodes works on the importing side).  rt_import_scene replaces the context's scene with the block's
- * (copied to the device during the call; the block may be a read-only shared mapping); materials, textures, camera
+ * (copied to the device during the call; the block may be a read-only shared mapping) after checking it on the host:
+ * layout version and record sizes of the writing build, a checksum of the payload, every child reference and primitive
+ * range, the depth against the announced stack (a stale, torn or foreign block is RT_E_ARG, not a fault in the kernel); materials, textures, camera
  * and options are not part of it.  An imported scene cannot be re-laid-out: changing RT_OPT_LEAF_SIZE / BOX_MODE /
  * TOPOLOGY / COLLAPSE afterwards is an error at the next render. */
 int rt_export_scene(rt_ctx *ctx, int flags, void *out, uint64_t cap, uint64_t *bytes);
@@ -184,8 +186,11 @@ int rt_render(rt_ctx *ctx, float *fb_rgb_host, rt_stats *stats);
  * device); the call returns after the kernel has completed. */
 int rt_render_device(rt_ctx *ctx, float *fb_rgb_device, rt_stats *stats);
 
-/* rt_render_device for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same frame (bit for bit), same
+/* rt_render_device for callers that cannot allocate device memory: tight serving loops, harnesses that forbid
+ * hipMalloc, processes that must keep their device-memory footprint fixed.  No counterpart in the reference.  It is
+ * NOT usable under HIP stream capture: like rt_render_device it runs on the context's own stream, issues
+ * hipMemsetAsync for its counters (and, once per 2^26 frames of a device, for the record area), synchronises that
+ * stream, reads the event timer and copies the ray counter back -- all illegal or unrecorded while a capture is open.  Same arguments, same frame (bit for bit), same
  * kernels as rt_render_device, but every scratch buffer of the launch -- band counters, ray counter, the traversal
  * stacks' spill area, the round records -- comes out of ONE static device array of 64 MiB that the library holds on
  * every GPU it runs on until the process ends, and the call itself makes no hipMalloc / hipFree and uploads nothing:
@@ -232,6 +237,12 @@ int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *
 int rt_test_scene_blob(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size, int box_mode,
                        int topology, int flags, void *out, uint64_t cap, uint64_t *bytes);
 int rt_test_scene_blob_info(const void *blob, uint64_t bytes, uint64_t info[16]);
+/* What rt_import_scene checks before anything reaches the GPU, alone (no GPU needed): the header (magic, layout version,
+ * record sizes of the writing build, counts against the length), the payload's checksum, and one pass over the sections
+ * (every child reference names a later node or a primitive range inside the array, the implied depth fits the announced
+ * stack, material / texture indices in range).  RT_OK, or RT_E_ARG with the reason in err_out.  rehash != 0 first
+ * rewrites the header's checksum from the payload as it is (tests: an edited block that still passes the checksum). */
+int rt_test_scene_blob_check(void *blob, uint64_t bytes, int rehash, char *err_out, int err_cap);
 
 /* The tile-sharding rule alone (no GPU needed): owner[j*nx+i] = rank that renders pixel (i, j) when the frame
  * is split over `world` contexts (RT_OPT_SHARD_RANK / RT_OPT_SHARD_WORLD). */

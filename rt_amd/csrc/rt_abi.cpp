@@ -13,6 +13,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bvh_build.h"
@@ -219,13 +220,20 @@ int upload_scene(rt_ctx *c) {
 // header (256 bytes), then the sections in this order, each starting on a multiple of 256 bytes:
 // quantised nodes, primitives, shading records, texture coordinates, [float nodes], [reference binary nodes]
 struct SceneBlobHeader {
-    char magic[8]; // "RTAMDSC1"
+    char magic[8]; // "RTAMDSC2"
     uint64_t n_wide, n_prims, n_uv, n_float_nodes, n_bnodes, total_bytes;
     int32_t depth, stack_entries;
     float pad;
     int32_t reserved;
+    // what the writing build laid out: a block from another build of the library (other record sizes, another node
+    // encoding) is refused instead of being traversed
+    uint32_t layout_version;
+    uint32_t sz_qnode, sz_prim, sz_shade, sz_uv, sz_fnode, sz_bnode;
+    uint32_t reserved2;
+    uint64_t payload_hash; // blob_hash over bytes [kBlobAlign, total_bytes)
 };
 static_assert(sizeof(SceneBlobHeader) <= 256, "scene blob header");
+constexpr uint32_t kBlobLayoutVersion = 2; // bump whenever QuantNode / DevPrim / DevShade / DevUV or the child-reference encoding change
 constexpr uint64_t kBlobAlign = 256;
 inline uint64_t blob_round(uint64_t b) { return (b + kBlobAlign - 1) / kBlobAlign * kBlobAlign; }
 struct SceneBlobLayout {
@@ -243,12 +251,43 @@ SceneBlobLayout blob_layout(const SceneBlobHeader &h) {
     L.total = at;
     return L;
 }
+// Hash of a block's payload (every byte is a multiple of 256 from the block's start, so 8-byte words): a multiply-xor
+// chain per 4 MiB chunk, chunks hashed on up to eight threads (the 100 M-triangle block is 8 GB) and folded in order.
+// Not cryptographic: it catches truncated-then-padded, stale and torn blocks, which is what a file in /dev/shm can be.
+uint64_t blob_hash_words(const unsigned char *p, uint64_t bytes, uint64_t seed) {
+    uint64_t h = seed ^ 0x9E3779B97F4A7C15ull;
+    for (uint64_t i = 0; i + 8 <= bytes; i += 8) {
+        uint64_t w;
+        std::memcpy(&w, p + i, 8);
+        h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29;
+    }
+    return h;
+}
+uint64_t blob_hash(const void *payload, uint64_t bytes) {
+    constexpr uint64_t kChunk = (uint64_t)4 << 20;
+    const unsigned char *p = static_cast<const unsigned char *>(payload);
+    const uint64_t n_chunks = (bytes + kChunk - 1) / kChunk;
+    std::vector<uint64_t> part(n_chunks);
+    const unsigned n_threads = (unsigned)std::min<uint64_t>(8, std::max<uint64_t>(1, n_chunks / 4));
+    auto work = [&](unsigned t) {
+        for (uint64_t c = t; c < n_chunks; c += n_threads) part[c] = blob_hash_words(p + c * kChunk, std::min(kChunk, bytes - c * kChunk), c);
+    };
+    if (n_threads <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < n_threads; t++) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    return blob_hash_words(reinterpret_cast<const unsigned char *>(part.data()), n_chunks * 8, bytes);
+}
 // flags: bit 0 = with the 128-byte float nodes (RT_OPT_NODE_FORMAT 0 and kernel variant 0 need them), bit 1 = with the
 // reference's binary node array (rt_get_bvh_nodes on the importing side)
 int write_scene_blob(const WideBvh &w, const std::vector<rt_bvh_node32> &bnodes, int flags, void *out, uint64_t cap, uint64_t *bytes) {
     SceneBlobHeader h;
     std::memset(&h, 0, sizeof(h));
-    std::memcpy(h.magic, "RTAMDSC1", 8);
+    std::memcpy(h.magic, "RTAMDSC2", 8);
     h.n_wide = w.qnodes.size();
     h.n_prims = w.prims.size();
     h.n_uv = w.uv.size();
@@ -257,33 +296,97 @@ int write_scene_blob(const WideBvh &w, const std::vector<rt_bvh_node32> &bnodes,
     h.depth = w.depth;
     h.stack_entries = w.stack_entries;
     h.pad = w.pad;
+    h.layout_version = kBlobLayoutVersion;
+    h.sz_qnode = sizeof(QuantNode), h.sz_prim = sizeof(DevPrim), h.sz_shade = sizeof(DevShade), h.sz_uv = sizeof(DevUV);
+    h.sz_fnode = sizeof(WideNode), h.sz_bnode = sizeof(rt_bvh_node32);
     const SceneBlobLayout L = blob_layout(h);
     h.total_bytes = L.total;
     if (bytes) *bytes = L.total;
     if (!out) return RT_OK; // size query
     if (cap < L.total) return RT_E_ARG;
     char *o = static_cast<char *>(out);
+    // a section is copied and the rest of its 256-byte-aligned slot zeroed: the hash covers every byte of the payload
+    auto put_section = [&](uint64_t at, uint64_t next, const void *src, uint64_t n) {
+        if (n) std::memcpy(o + at, src, n);
+        if (next > at + n) std::memset(o + at + n, 0, next - at - n);
+    };
+    put_section(L.qnodes, L.prims, w.qnodes.data(), h.n_wide * sizeof(QuantNode));
+    put_section(L.prims, L.shade, w.prims.data(), h.n_prims * sizeof(DevPrim));
+    put_section(L.shade, L.uv, w.shade.data(), h.n_prims * sizeof(DevShade));
+    put_section(L.uv, L.fnodes, w.uv.data(), h.n_uv * sizeof(DevUV));
+    put_section(L.fnodes, L.bnodes, w.nodes.data(), h.n_float_nodes * sizeof(WideNode));
+    put_section(L.bnodes, L.total, bnodes.data(), h.n_bnodes * sizeof(rt_bvh_node32));
+    h.payload_hash = blob_hash(o + kBlobAlign, L.total - kBlobAlign);
     std::memset(o, 0, kBlobAlign);
     std::memcpy(o, &h, sizeof(h));
-    std::memcpy(o + L.qnodes, w.qnodes.data(), h.n_wide * sizeof(QuantNode));
-    std::memcpy(o + L.prims, w.prims.data(), h.n_prims * sizeof(DevPrim));
-    std::memcpy(o + L.shade, w.shade.data(), h.n_prims * sizeof(DevShade));
-    if (h.n_uv) std::memcpy(o + L.uv, w.uv.data(), h.n_uv * sizeof(DevUV));
-    if (h.n_float_nodes) std::memcpy(o + L.fnodes, w.nodes.data(), h.n_float_nodes * sizeof(WideNode));
-    if (h.n_bnodes) std::memcpy(o + L.bnodes, bnodes.data(), h.n_bnodes * sizeof(rt_bvh_node32));
     return RT_OK;
 }
-// checks a blob's header against its length; err names what is wrong
+// checks a blob's header against its length and against this build's record layout; err names what is wrong
 bool read_scene_blob_header(const void *blob, uint64_t bytes, SceneBlobHeader &h, SceneBlobLayout &L, std::string &err) {
     if (!blob || bytes < kBlobAlign) return err = "scene blob too short", false;
     std::memcpy(&h, blob, sizeof(h));
-    if (std::memcmp(h.magic, "RTAMDSC1", 8) != 0) return err = "not a scene blob (bad magic)", false;
+    if (std::memcmp(h.magic, "RTAMDSC", 7) == 0 && h.magic[7] != '2') return err = "scene blob of another layout version (magic)", false;
+    if (std::memcmp(h.magic, "RTAMDSC2", 8) != 0) return err = "not a scene blob (bad magic)", false;
+    if (h.layout_version != kBlobLayoutVersion || h.sz_qnode != sizeof(QuantNode) || h.sz_prim != sizeof(DevPrim) ||
+        h.sz_shade != sizeof(DevShade) || h.sz_uv != sizeof(DevUV) || h.sz_fnode != sizeof(WideNode) || h.sz_bnode != sizeof(rt_bvh_node32))
+        return err = "scene blob was written by another build of the library (layout version / record sizes differ)", false;
     if (h.n_wide == 0 || h.n_prims == 0 || h.n_wide > ((uint64_t)1 << 26) || h.n_prims > 0x0FFFFFFFull ||
         (h.n_uv != 0 && h.n_uv != h.n_prims) || (h.n_float_nodes != 0 && h.n_float_nodes != h.n_wide) ||
         h.n_bnodes > 0x7FFFFFFFull || h.stack_entries < 1 || (uint64_t)h.stack_entries * 256 > 64 * 1024)
         return err = "scene blob header out of range", false;
     L = blob_layout(h);
     if (L.total != h.total_bytes || bytes < L.total) return err = "scene blob truncated", false;
+    return true;
+}
+// The sections themselves, before any of it reaches the GPU: the payload hash, then one pass over the quantised nodes
+// and the per-primitive records.  Every child reference must name a later node (the layout is breadth-first: that also
+// rules out cycles) or a primitive range inside the array; the depth the references imply must fit the stack the
+// header announces (3 entries per level + 2: wide_bvh.cpp); material and texture indices must be in range.  A corrupt
+// block is an RT_E_ARG here instead of an out-of-bounds read or a stack overflow inside the traversal kernel.
+bool validate_scene_blob(const void *blob, const SceneBlobHeader &h, const SceneBlobLayout &L, std::string &err) {
+    const char *b = static_cast<const char *>(blob);
+    if (blob_hash(b + kBlobAlign, L.total - kBlobAlign) != h.payload_hash) return err = "scene blob payload does not match its checksum (stale, torn or padded block)", false;
+    const QuantNode *q = reinterpret_cast<const QuantNode *>(b + L.qnodes);
+    std::vector<int32_t> level(h.n_wide, 0);
+    std::vector<uint8_t> covered; // primitives under some leaf
+    level[0] = 1;
+    int32_t max_level = 1;
+    uint64_t prims_in_leaves = 0;
+    for (uint64_t i = 0; i < h.n_wide; i++) {
+        if (level[i] == 0) return err = "scene blob: wide node " + std::to_string(i) + " is not referenced by an earlier node", false;
+        max_level = std::max(max_level, level[i]);
+        for (int s = 0; s < 4; s++) {
+            const uint32_t r = q[i].child[s];
+            if (r == kEmptyRef) continue;
+            if (r & kLeafBit) {
+                const uint64_t start = r & kLeafStartMask, cnt = ((r >> 28) & 7u) + 1u;
+                if (start + cnt > h.n_prims) return err = "scene blob: leaf of wide node " + std::to_string(i) + " reaches beyond the primitive array", false;
+                prims_in_leaves += cnt;
+            } else {
+                if ((uint64_t)r >= h.n_wide || (uint64_t)r <= i) return err = "scene blob: child reference of wide node " + std::to_string(i) + " out of range", false;
+                if (level[r] != 0) return err = "scene blob: wide node " + std::to_string(r) + " is referenced twice", false;
+                level[r] = level[i] + 1;
+            }
+        }
+    }
+    if (prims_in_leaves != h.n_prims) return err = "scene blob: leaves do not cover the primitive array exactly once", false;
+    if (3 * (int64_t)max_level + 2 > (int64_t)h.stack_entries || max_level > h.depth)
+        return err = "scene blob: tree is deeper than the header says (traversal stack would overflow)", false;
+    const DevShade *sh = reinterpret_cast<const DevShade *>(b + L.shade);
+    for (uint64_t i = 0; i < h.n_prims; i++)
+        if (sh[i].mat < 0 || sh[i].mat >= RT_MAT_NUM) return err = "scene blob: material index out of range", false;
+    const DevPrim *pr = reinterpret_cast<const DevPrim *>(b + L.prims);
+    for (uint64_t i = 0; i < h.n_prims; i++)
+        if (pr[i].shape != 0 && pr[i].shape != 1) return err = "scene blob: primitive shape must be 0 or 1", false;
+    const DevUV *uv = reinterpret_cast<const DevUV *>(b + L.uv);
+    for (uint64_t i = 0; i < h.n_uv; i++)
+        if (uv[i].tex < -1 || uv[i].tex >= RT_TEX_NUM) return err = "scene blob names a texture index out of range", false;
+    if (h.n_float_nodes) { // the float copy carries the same references
+        const WideNode *w = reinterpret_cast<const WideNode *>(b + L.fnodes);
+        for (uint64_t i = 0; i < h.n_wide; i++)
+            if (std::memcmp(w[i].child, q[i].child, sizeof(q[i].child)) != 0) return err = "scene blob: float and quantised nodes disagree", false;
+    }
+    if (h.n_bnodes && h.n_bnodes != 2 * h.n_prims - 1) return err = "scene blob: binary node count must be 2n-1", false;
     return true;
 }
 
@@ -1187,7 +1290,7 @@ int rt_import_scene(rt_ctx *c, const void *blob, uint64_t bytes) {
     SceneBlobHeader h;
     SceneBlobLayout L;
     std::string err;
-    if (!read_scene_blob_header(blob, bytes, h, L, err)) return fail(c, RT_E_ARG, err);
+    if (!read_scene_blob_header(blob, bytes, h, L, err) || !validate_scene_blob(blob, h, L, err)) return fail(c, RT_E_ARG, err);
     HIPCHK(c, hipSetDevice(c->device));
     const char *b = static_cast<const char *>(blob);
     free_scene(c);
@@ -1207,11 +1310,6 @@ int rt_import_scene(rt_ctx *c, const void *blob, uint64_t bytes) {
         HIPCHK(c, hipMemcpy(c->d_uv, b + L.uv, h.n_uv * sizeof(DevUV), hipMemcpyHostToDevice));
         c->wide.uv.resize(h.n_uv); // kept on the host: which textures the scene names (check_textures)
         std::memcpy(c->wide.uv.data(), b + L.uv, h.n_uv * sizeof(DevUV));
-        for (const DevUV &q : c->wide.uv)
-            if (q.tex < -1 || q.tex >= RT_TEX_NUM) {
-                free_scene(c);
-                return fail(c, RT_E_ARG, "scene blob names a texture index out of range");
-            }
     }
     if (h.n_float_nodes) {
         HIPCHK(c, hipMalloc(&c->d_nodes, h.n_float_nodes * sizeof(WideNode)));
@@ -1241,16 +1339,34 @@ int rt_test_scene_blob(const rt_triangle148 *tris, int n, const rt_bvh_node32 *n
     RT_CATCH(nullptr)
 }
 
-int rt_test_scene_blob_info(const void *blob, uint64_t bytes, uint64_t info[16]) {
-    if (!info) return RT_E_ARG;
+int rt_test_scene_blob_check(void *blob, uint64_t bytes, int rehash, char *err_out, int err_cap) {
+    RT_TRY
     SceneBlobHeader h;
     SceneBlobLayout L;
     std::string err;
-    if (!read_scene_blob_header(blob, bytes, h, L, err)) return RT_E_ARG;
+    bool ok = read_scene_blob_header(blob, bytes, h, L, err);
+    if (ok && rehash) { // tests: make an edited payload pass the checksum, so that the structural checks are what refuses it
+        h.payload_hash = blob_hash(static_cast<const char *>(blob) + kBlobAlign, L.total - kBlobAlign);
+        std::memcpy(blob, &h, sizeof(h));
+    }
+    ok = ok && validate_scene_blob(blob, h, L, err);
+    if (err_out && err_cap > 0) std::snprintf(err_out, (size_t)err_cap, "%s", ok ? "" : err.c_str());
+    return ok ? RT_OK : RT_E_ARG;
+    RT_CATCH(nullptr)
+}
+
+int rt_test_scene_blob_info(const void *blob, uint64_t bytes, uint64_t info[16]) {
+    if (!info) return RT_E_ARG;
+    RT_TRY
+    SceneBlobHeader h;
+    SceneBlobLayout L;
+    std::string err;
+    if (!read_scene_blob_header(blob, bytes, h, L, err) || !validate_scene_blob(blob, h, L, err)) return RT_E_ARG;
     const uint64_t v[16] = {h.n_wide, h.n_prims, h.n_uv, h.n_float_nodes, h.n_bnodes, h.total_bytes, (uint64_t)h.depth,
-                            (uint64_t)h.stack_entries, L.qnodes, L.prims, L.shade, L.uv, L.fnodes, L.bnodes, 0, 0};
+                            (uint64_t)h.stack_entries, L.qnodes, L.prims, L.shade, L.uv, L.fnodes, L.bnodes, h.payload_hash, h.layout_version};
     std::memcpy(info, v, sizeof(v));
     return RT_OK;
+    RT_CATCH(nullptr)
 }
 
 int rt_test_trav_stats(rt_ctx *c, uint64_t out[40]) {

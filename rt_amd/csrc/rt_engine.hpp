@@ -155,6 +155,13 @@ class PbrtEngine {
     template <class M, class B, class T> static void gen(M *m, void (B::*f)(std::vector<T> &) const, std::vector<rt_triangle148> &out) {
         gen_into<T>(out, [&](std::vector<T> &v) { (m->*f)(v); });
     }
+    // the reference's own signature: virtual void genTriangles(std::vector<Triangle>&, bool _setNormal = false) (include/RT/mesh.h:241)
+    template <class M, class B, class T> static void gen(M *m, void (B::*f)(std::vector<T> &, bool), std::vector<rt_triangle148> &out) {
+        gen_into<T>(out, [&](std::vector<T> &v) { (m->*f)(v, false); });
+    }
+    template <class M, class B, class T> static void gen(M *m, void (B::*f)(std::vector<T> &, bool) const, std::vector<rt_triangle148> &out) {
+        gen_into<T>(out, [&](std::vector<T> &v) { (m->*f)(v, false); });
+    }
     template <class T, class F> static void gen_into(std::vector<rt_triangle148> &out, F call) {
         static_assert(sizeof(T) == sizeof(rt_triangle148), "genTriangles must emit the reference's 148-byte Triangle");
         std::vector<T> tmp;

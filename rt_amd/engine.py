@@ -73,7 +73,7 @@ ABI_SYMBOLS = [
     "rt_write_ppm", "rt_test_glibc_rand", "rt_test_introsort", "rt_test_build_bvh", "rt_test_wide_layout", "rt_test_tile_owner", "rt_test_fastdiv",
     "rt_test_trav_stats", "rt_test_sincosf", "rt_set_texture", "rt_trace_rays_device", "rt_test_dump_rays", "rt_test_wave_times",
     "rt_test_trace_dumped", "rt_render_device_noalloc", "rt_test_sort_dumped", "rt_export_scene", "rt_import_scene",
-    "rt_test_scene_blob", "rt_test_scene_blob_info",
+    "rt_test_scene_blob", "rt_test_scene_blob_info", "rt_test_scene_blob_check",
 ]
 
 
@@ -109,6 +109,7 @@ def load_library(path: str = LIB_PATH):
     lib.rt_import_scene.argtypes = [vp, vp, C.c_uint64]
     lib.rt_test_scene_blob.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.rt_test_scene_blob_info.argtypes = [vp, C.c_uint64, vp]
+    lib.rt_test_scene_blob_check.argtypes = [vp, C.c_uint64, C.c_int, C.c_char_p, C.c_int]
     lib.rt_set_option.argtypes = [vp, C.c_int, C.c_int64]
     lib.rt_get_option.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
     lib.rt_render.argtypes = [vp, vp, C.POINTER(RtStats)]
@@ -218,6 +219,16 @@ def scene_blob_info(blob: np.ndarray):
     keys = ["wide_nodes", "prims", "uv", "float_nodes", "binary_nodes", "total_bytes", "depth", "stack_entries",
             "off_qnodes", "off_prims", "off_shade", "off_uv", "off_float_nodes", "off_binary_nodes"]
     return {k: int(v) for k, v in zip(keys, info)}
+
+
+def scene_blob_check(blob: np.ndarray, rehash: bool = False) -> str:
+    """"" if rt_import_scene would accept the block, else the reason it gives.  rehash: first rewrite the header's
+    checksum from the payload as it is (in place), so that an edited block is judged by the structural checks."""
+    lib = load_library()
+    assert blob.dtype == np.uint8 and blob.flags["C_CONTIGUOUS"]
+    buf = C.create_string_buffer(512)
+    rc = lib.rt_test_scene_blob_check(_ptr(blob), blob.nbytes, 1 if rehash else 0, buf, 512)
+    return "" if rc == 0 else (buf.value.decode() or f"error {rc}")
 
 
 def write_ppm(path: str, fb: np.ndarray) -> None:

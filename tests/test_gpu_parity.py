@@ -710,6 +710,55 @@ def test_bench_frame_64spp_lattice(oracle):
     sub = (slice(lat[1], None, lat[3]), slice(lat[0], None, lat[2]))
     assert cnt.rays > 1_000_000
     assert fb[sub].tobytes() == fb_o[sub].tobytes()
+    # every hand-off of the frame, not only those of the lattice's pixels: the same frame in ONE round (no pixel state
+    # ever leaves its lane) is the same 24.9 MB, byte for byte -- 14.5 M hand-offs per frame, each of which would
+    # change a pixel if one word of one record arrived stale or torn
+    rays = eng.last_stats.rays
+    eng.setOption(engine.OPT_TAIL_SPLIT, 1)
+    one_round = eng.render()
+    assert eng.last_stats.rays == rays
+    assert one_round.tobytes() == fb.tobytes()
+    eng.close()
+
+
+def test_4k_frame_rounds_whole_frame():
+    """The 3840x2160 frame of BASELINE config 4 at 64 spp: the launch picks 2 rounds there (a different hand-off
+    schedule from the 8 rounds of 1080p).  Default rounds, one round and eight forced rounds give the same 99.5 MB."""
+    tris = scenes.heightfield(708)
+    eng = _engine(tris, 3840, 2160, 64, 8, scenes.BENCH_CAMERA)
+    fb = eng.render()
+    rays = eng.last_stats.rays
+    for rounds in (1, 8):
+        eng.setOption(engine.OPT_TAIL_SPLIT, rounds)
+        other = eng.render()
+        assert eng.last_stats.rays == rays, rounds
+        assert other.tobytes() == fb.tobytes(), rounds
+    eng.close()
+
+
+def test_cfg4_full_1024spp_lattice_and_whole_frame(oracle):
+    """BASELINE config 4 at its stated size on one GPU: the 1 M-triangle scene, 3840x2160, 1024 spp, depth 8 (18.4 G
+    rays, ~2 s per launch).  The frame against the oracle at the real 1024 spp on every 64th pixel of every 64th row
+    (2 040 pixels, ~4.6 M rays), bit for bit -- what `bench.py --strong` reports as lattice_parity -- and the whole frame
+    against the same frame rendered in one round."""
+    tris = scenes.heightfield(708)
+    nx, ny, ns, depth = 3840, 2160, 1024, 8
+    eng = _engine(tris, nx, ny, ns, depth, scenes.BENCH_CAMERA)
+    fb = eng.render()
+    rays = eng.last_stats.rays
+    assert 15_000_000_000 < rays < 25_000_000_000
+    nodes = eng.getBvhNodes()
+    cam = scenes.BENCH_CAMERA
+    ocam = oracle.camera(cam["lookfrom"], cam["lookat"], 40.0, nx / ny, 0.0, 10.0)
+    lat = (32, 32, 64, 64)
+    fb_o, cnt = oracle.render(tris, nodes, oracle.material_table(), ocam, nx, ny, ns, depth, mode=1, threads=16, lattice=lat)
+    sub = (slice(lat[1], None, lat[3]), slice(lat[0], None, lat[2]))
+    assert cnt.rays > 3_000_000
+    assert fb[sub].tobytes() == fb_o[sub].tobytes()
+    eng.setOption(engine.OPT_TAIL_SPLIT, 1)
+    one_round = eng.render()
+    assert eng.last_stats.rays == rays
+    assert one_round.tobytes() == fb.tobytes()
     eng.close()
 
 
@@ -740,43 +789,6 @@ def test_cfg4_4k_frame_tile_sharded(oracle):
     fb_o, _ = oracle.render(tris, nodes, oracle.material_table(), ocam, nx, ny, ns, depth, mode=1, threads=16, lattice=lat)
     sub = (slice(lat[1], None, lat[3]), slice(lat[0], None, lat[2]))
     assert whole[sub].tobytes() == fb_o[sub].tobytes()
-    eng.close()
-
-
-def test_big_scene_cfg5(oracle):
-    """BASELINE config 5's kind of scene on one GPU: a G x G heightfield far beyond the caches, 1080p, 16 spp, depth 8,
-    BVH replicated per GPU.  Default G = 2236 (9 999 394 triangles: 1.5 GB of records, seconds to build);
-    RT_BIG_GRID=7072 runs the full 100 026 370 triangles (minutes, ~100 GB of host memory).  The frame is checked
-    against the oracle on a sparse pixel lattice (the oracle traverses the product's reference-tree nodes; its own
-    serial builder would take tens of minutes at the full size)."""
-    import time
-
-    G = int(os.environ.get("RT_BIG_GRID", "2236"))
-    t0 = time.time()
-    tris = scenes.heightfield(G)
-    t1 = time.time()
-    eng = rt_amd.PbrtEngine(1920, 1080, 16, device=0)
-    eng.setTriangles(tris)
-    eng.buildBvh()
-    t2 = time.time()
-    eng.setMaxDepth(8)
-    eng.setCamera(**scenes.BENCH_CAMERA)
-    fb = eng.render()
-    st = eng.last_stats
-    print(f"\nBIG: {tris.shape[0]} triangles, scene {t1 - t0:.1f}s, build+layout+upload {t2 - t1:.1f}s, wide nodes {st.wide_nodes}, "
-          f"stack {st.stack_entries}, render {st.kernel_ms:.1f} ms, {st.rays} rays, {st.rays / st.kernel_ms / 1e3:.0f} Mrays/s")
-    ids, ts = eng.tracePrimary()
-    print(f"BIG: primary {eng.last_stats.kernel_ms:.2f} ms = {1920 * 1080 / eng.last_stats.kernel_ms / 1e3:.0f} Mrays/s")
-    nodes = eng.getBvhNodes()
-    cam = scenes.BENCH_CAMERA
-    ocam = oracle.camera(cam["lookfrom"], cam["lookat"], 40.0, 1920 / 1080, 0.0, 10.0)
-    lat = (11, 5, 60, 60)
-    fb_o, _ = oracle.render(tris, nodes, oracle.material_table(), ocam, 1920, 1080, 16, 8, mode=1, threads=16, lattice=lat)
-    sub = (slice(lat[1], None, lat[3]), slice(lat[0], None, lat[2]))
-    assert fb[sub].tobytes() == fb_o[sub].tobytes()
-    ids_o, ts_o, _ = oracle.trace_primary(tris, nodes, ocam, 1920, 1080, mode=1, threads=16, lattice=(3, 3, 20, 20))
-    sub = (slice(3, None, 20), slice(3, None, 20))
-    assert (ids[sub] != ids_o[sub]).sum() == 0 and ts[sub].tobytes() == ts_o[sub].tobytes()
     eng.close()
 
 

@@ -371,6 +371,71 @@ def test_scene_blob_round_trip(flags):
     assert engine.scene_blob_info(bad) is None
 
 
+def test_scene_blob_with_valid_header_and_corrupt_sections_is_refused():
+    """a block whose header is fine but whose sections are not -- stale, torn, padded after a truncation, or
+    written by another build -- must be an RT_E_ARG on the host, not out-of-bounds reads or a stack overflow in the
+    traversal kernel.  First line of defence: the payload checksum.  Second (shown by re-hashing the edited block): the
+    structural pass over child references, leaf ranges, depth, material and texture indices."""
+    tris = scenes.heightfield(12).copy()
+    tris["texIdx"][7] = 2
+    nodes = engine.host_build_bvh(tris)
+    blob = engine.host_scene_blob(tris, nodes, flags=3)
+    info = engine.scene_blob_info(blob)
+    assert engine.scene_blob_check(blob.copy()) == ""
+    q0 = info["off_qnodes"]
+
+    def child_words(b, node):  # the four child references of a 64-byte quantised node
+        return b[q0 + 64 * node + 48:q0 + 64 * node + 64].view(np.uint32)
+
+    # any flipped payload bit: the checksum
+    bad = blob.copy()
+    bad[info["off_prims"] + 5] ^= 0x10
+    assert "checksum" in engine.scene_blob_check(bad) and engine.scene_blob_info(bad) is None
+    # a truncated-then-padded block: the tail zeroed
+    bad = blob.copy()
+    bad[-4096:] = 0
+    assert "checksum" in engine.scene_blob_check(bad)
+    # child reference beyond the node array (valid header, valid checksum after the re-hash)
+    bad = blob.copy()
+    refs = child_words(bad, 0)
+    inner = [k for k in range(4) if refs[k] != 0xFFFFFFFF and not refs[k] & 0x80000000]
+    assert inner
+    refs[inner[0]] = info["wide_nodes"] + 3
+    assert "out of range" in engine.scene_blob_check(bad, rehash=True)
+    assert engine.scene_blob_check(bad) != ""  # and without the re-hash the checksum already refuses it
+    # a reference back to the root: a cycle
+    bad = blob.copy()
+    child_words(bad, 1)[0] = 0
+    assert engine.scene_blob_check(bad, rehash=True) != ""
+    # a leaf range that runs off the primitive array
+    bad = blob.copy()
+    last = info["wide_nodes"] - 1
+    refs = child_words(bad, last)
+    leaf = [k for k in range(4) if refs[k] != 0xFFFFFFFF and refs[k] & 0x80000000]
+    refs[leaf[0]] = 0x80000000 | (7 << 28) | (info["prims"] - 2)
+    assert "primitive array" in engine.scene_blob_check(bad, rehash=True)
+    # a stack announcement smaller than the tree needs
+    bad = blob.copy()
+    bad[8 + 6 * 8 + 4:8 + 6 * 8 + 8].view(np.int32)[0] = 4  # stack_entries
+    assert "deeper" in engine.scene_blob_check(bad, rehash=True)
+    # material and texture indices
+    bad = blob.copy()
+    bad[info["off_shade"] + 16 * 9 + 12:info["off_shade"] + 16 * 9 + 16].view(np.int32)[0] = 50
+    assert "material" in engine.scene_blob_check(bad, rehash=True)
+    bad = blob.copy()
+    bad[info["off_uv"] + 32 * 3 + 24:info["off_uv"] + 32 * 3 + 28].view(np.int32)[0] = 16
+    assert "texture" in engine.scene_blob_check(bad, rehash=True)
+    # a block from another build: other record sizes / layout version
+    bad = blob.copy()
+    bad[7] = ord("1")
+    assert "layout version" in engine.scene_blob_check(bad, rehash=True)
+    bad = blob.copy()
+    hdr = bad[:256].view(np.uint32)
+    assert hdr[18] == 2 and hdr[19] == 64 and hdr[20] == 48  # layout_version, sizeof(QuantNode), sizeof(DevPrim)
+    hdr[19] = 48
+    assert "another build" in engine.scene_blob_check(bad, rehash=True)
+
+
 def test_scene_blob_carries_texture_coordinates():
     tris = scenes.heightfield(6).copy()
     tris["texIdx"][5] = 3
@@ -379,3 +444,40 @@ def test_scene_blob_carries_texture_coordinates():
     nodes = engine.host_build_bvh(tris)
     info = engine.scene_blob_info(engine.host_scene_blob(tris, nodes))
     assert info["uv"] == info["prims"] == tris.shape[0]
+
+
+def test_shim_accepts_the_reference_mesh_signature(tmp_path):
+    """ADVICE r02: PbrtEngine::addMesh of the C++ shim must take a class with the REFERENCE's signature,
+    `virtual void genTriangles(std::vector<Triangle>&, bool _setNormal = false)` (include/RT/mesh.h:241), as well as
+    rtscene::Mesh's one-argument form, const or not.  Compile-only (no GPU, nothing linked)."""
+    import shutil
+    import subprocess
+
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        pytest.fail("no host C++ compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "mock.cpp"
+    src.write_text('''
+#include "rt_amd/csrc/rt_engine.hpp"
+struct Triangle { float f[33]; int calNormal, matType, shapeType, texIdx; };   // 148 bytes, as triangle.h:345-354
+static_assert(sizeof(Triangle) == 148, "mock record");
+struct RefMesh {                                    // the reference's Mesh, as far as the engine sees it
+    virtual ~RefMesh() {}
+    std::string getName() { return "light"; }
+    virtual void genTriangles(std::vector<Triangle>& v, bool _setNormal = false) { (void)_setNormal; v.emplace_back(); }
+};
+struct ConstMesh {
+    const char* getName() const { return "c"; }
+    void genTriangles(std::vector<Triangle>& v, bool) const { v.emplace_back(); }
+};
+struct OneArg {
+    std::string getName() const { return "o"; }
+    void genTriangles(std::vector<rt_triangle148>& v) const { v.emplace_back(); }
+};
+void use(PbrtEngine& e, RefMesh* a, ConstMesh* b, OneArg* c, std::vector<RefMesh*>& all) {
+    e.addMesh(a); e.addMesh(b); e.addMesh(c); e.addMesh(all);
+}
+''')
+    out = subprocess.run([cxx, "-std=c++17", "-fsyntax-only", "-I", root, str(src)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-3000:]
