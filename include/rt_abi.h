@@ -71,7 +71,8 @@ typedef struct rt_stats {
     uint64_t wide_nodes;  /* device BVH size */
     uint64_t prims;
     int32_t stack_entries; /* LDS stack entries per lane */
-    int32_t reserved;
+    int32_t handoff_torn; /* render in rounds: polls of a pixel-state record that found an 8-byte granule whose two words
+                             were not from one store (detected by the check word, read again); 0 is what gfx950 has shown */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;
@@ -174,7 +175,13 @@ enum {
     RT_OPT_PRIMARY_WAVES = 22,   /* rt_trace_primary*: most persistent waves per CU, 1..32 (default 16; a 1080p frame gets 8) */
     RT_OPT_PRIMARY_CHUNK = 23,   /* rt_trace_primary*: pixel slots a wave takes per atomic, a multiple of 64 (default 256) */
     RT_OPT_TAIL_TAPER = 24,      /* rounds: sample boundary r at ns (1 - (1 - r/R)^(value/100)); 100 = equal shares, more = short last rounds (default 150) */
-    RT_OPT_COLLAPSE = 25         /* device tree: 0 = wide nodes by largest-area expansion, 1 = by least surface-area cost (dynamic programme; default) */
+    RT_OPT_COLLAPSE = 25,        /* device tree: 0 = wide nodes by largest-area expansion, 1 = by least surface-area cost (dynamic programme; default) */
+    RT_OPT_DETERMINISTIC = 26    /* 1 (default): a ray's traversal is a function of the ray and the tree alone, so a frame is the same bytes
+                                    launch after launch, whatever the rounds, waves and thresholds.  0: box tests cull against the freshest
+                                    hit, 5 % faster on the bench frame, and about one ray in 10^10 -- a grazing ray whose epsilon-free
+                                    Moeller-Trumbore t (triangle.h:137-156) lies outside its own triangle's box -- may resolve either way
+                                    depending on which lanes share its wave.  Either way those rays can differ from the
+                                    reference, which culls nothing. */
 };
 int rt_set_option(rt_ctx *ctx, int option, int64_t value);
 int rt_get_option(rt_ctx *ctx, int option, int64_t *value);

@@ -633,13 +633,31 @@ static V tex_fetch(int idx, float u, float v) {
     return mk(out[0], out[1], out[2]);
 }
 
+/* analysis hook (o_set_ray_log): every ray path_color traces, with its result, 8 floats each:
+ * origin, direction, hit id (as float bits, -1 = miss), t.  Single-threaded renders only. */
+float *g_ray_log = nullptr;
+uint64_t g_ray_log_cap = 0, g_ray_log_n = 0;
+inline void log_ray(const Ray &r, bool hit, const Rec &rec) {
+    if (!g_ray_log) return;
+    if (g_ray_log_n < g_ray_log_cap) {
+        float *o = g_ray_log + 8 * g_ray_log_n;
+        o[0] = r.o.x, o[1] = r.o.y, o[2] = r.o.z, o[3] = r.d.x, o[4] = r.d.y, o[5] = r.d.z;
+        int32_t id = hit ? rec.tri : -1;
+        std::memcpy(&o[6], &id, 4);
+        o[7] = hit ? rec.t : 0.0f;
+    }
+    g_ray_log_n++;
+}
+
 /* color(), pbrt_engine.cu:459-566 */
 V path_color(const Scene &sc, const o_mat *mats, int max_depth, int mode, const Ray &primary, Rng &g, o_counts &cnt) {
     Ray cur = primary;
     V thr = mk(1.0f, 1.0f, 1.0f);
     for (int i = 0; i < max_depth; i++) {
         Rec rec;
-        if (scene_hit(sc, mode, cur, 0.001f, FLT_MAX, rec, cnt)) {
+        const bool was_hit = scene_hit(sc, mode, cur, 0.001f, FLT_MAX, rec, cnt);
+        log_ray(cur, was_hit, rec);
+        if (was_hit) {
             const o_mat &m = mats[rec.mat];
             V alb = ld(m.albedo);
             if (m.kind == O_LAMBERTIAN) { /* material.h:95-116 */
@@ -1047,6 +1065,14 @@ void o_trace_primary(const o_tri148 *tris, int n_tris, const o_node32 *nodes, in
             cnt->tri_tests += c.tri_tests;
         }
     }
+}
+
+uint64_t o_set_ray_log(float *buf, uint64_t cap) {
+    const uint64_t n = g_ray_log_n;
+    g_ray_log = buf;
+    g_ray_log_cap = buf ? cap : 0;
+    g_ray_log_n = 0;
+    return n;
 }
 
 int o_write_ppm(const char *path, const float *fb, int nx, int ny) { /* pbrt_engine.cu:123-133 */

@@ -138,6 +138,11 @@ void o_trace_primary(const o_tri148 *tris, int n_tris, const o_node32 *nodes, in
                      int ny, int x0, int y0, int sx, int sy, int mode, int threads, int32_t *ids, float *ts,
                      o_counts *cnt);
 
+/* -- analysis: log every ray the following single-threaded o_render calls trace into buf (8 floats per ray: origin,
+ *    direction, hit id as int32 bits (-1 = miss), t; at most cap rays are stored).  Returns the number of rays seen
+ *    since the previous call; buf = NULL switches the log off. -- */
+uint64_t o_set_ray_log(float *buf, uint64_t cap);
+
 /* -- PPM writer, pbrt_engine.cu:123-133 -- */
 int o_write_ppm(const char *path, const float *fb, int nx, int ny);
 

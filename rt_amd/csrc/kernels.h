@@ -69,6 +69,8 @@ struct PersistLaunch {
     int grid_waves;
     int node_format; // 0 = WideNode (128 B float), 1 = QuantNode (64 B)
     int speculative; // 1 = postpone leaves (speculative traversal)
+    int deterministic = 1; // speculative traversal over quantised nodes: 1 = cull against a value that is refreshed at points of the
+                           // lane's own sequence only (reproducible results), 0 = against the freshest (RT_OPT_DETERMINISTIC)
     int leaf_batch;
     int primary_chunk = 256; // primary rays: slots per band-counter atomic (a multiple of 64)
     int occupancy; // 4, 6 or 8 waves per SIMD the kernel's registers are held to (quantized nodes only)
@@ -87,7 +89,8 @@ struct PersistLaunch {
     unsigned long long *wave_times = nullptr; // analysis builds: rt_test_wave_times
     unsigned long long *stats; // kTravStats counters, zeroed by the caller; only written by a -DRT_TRAV_STATS build
 };
-enum { kRingWords = 20 }; // ten 8-byte {value, tag} granules per pixel slot
+enum { kRingWords = 20 }; // ten 8-byte {value, check} granules per pixel slot
+enum { kTornCounter = 8 };  // band_counters[8]: polls of a round record in which a granule yielded a tag beyond the expected one (a torn granule)
 // Lane-occupancy counters of the persistent kernel (analysis builds only, `make STATS=1`; tools/trav_stats.py)
 enum { kStatIters = 0, kStatNodeLanes, kStatStalledLanes, kStatIdleLanes, kStatLeafFires, kStatLeafLanes, kStatLeafPrims,
        kStatRefills, kStatShadeLanes, kStatPrimaryLanes, kStatFetchLanes, kStatNodeIters, kStatRetiredLanes, kStatWaitLanes, kStatSpinPolls, kStatPollFails /* 15: polls of a round flag that found the record missing */,

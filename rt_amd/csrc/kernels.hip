@@ -637,10 +637,32 @@ __global__ void __launch_bounds__(64) k_render(KernelScene S, KernelFrame F, flo
 #define RT_PIN4(V) asm volatile("" ::"v"((V).x), "v"((V).y), "v"((V).z), "v"((V).w))
 
 #define RT_REF_NONE 0xFFFFFFFFu /* "no node": has the leaf bit set but is never a real leaf reference */
+
+// Deterministic culling.  A node step drops children whose box the ray enters beyond the closest hit so far.  With
+// speculative traversal WHEN a lane's parked leaf is tested depends on the other lanes of its wave (the batch fires
+// when enough of them hold one), so "so far" would depend on the company a ray keeps -- harmless while every
+// accepted hit lies inside its own leaf's box, because then no culled box can hold a closer one.  The reference's
+// Moeller-Trumbore (triangle.h:137-156, no determinant epsilon) breaks that for grazing rays: with |det| tiny the
+// computed t can lie BEFORE the ray even enters the triangle's box (measured on the 1 M-triangle scene: t = 2.06286
+// against a box entered at 2.06311; about one ray in 10^10).  The reference, which culls nothing, takes such a hit;
+// here it is taken if its leaf is reached before a hit in between is known -- a matter of timing.  So the value
+// culled against is refreshed only at a point of the lane's OWN sequence: when it parks the next leaf, by which time
+// every earlier leaf has been tested.  A ray's node visits, leaf tests and result are then a function of the ray and
+// the tree alone: frames are reproducible launch to launch and whatever the rounds, waves or thresholds.  (They still
+// differ from the reference's on those ~10^-10 of rays whose inconsistent hit a box test culls: DESIGN.md 3.)
+// (a template flag, DET, on the traversal code: RT_OPT_DETERMINISTIC 0 runs the instances without it, which cull against
+// the freshest value and take 5 % less time on the bench frame -- 37.0 against 39.0 ms -- at the price of that timing
+// dependence.  The non-speculative and float-node variants always cull deterministically.)
+#define RT_CULL_T(T) (DET ? (T).cull_t : (T).best_t)
+#define RT_CULL_SYNC(T)                                                                                                \
+    do {                                                                                                               \
+        if (DET) (T).cull_t = (T).best_t;                                                                              \
+    } while (0)
 struct Trav {
     float idx, idy, idz, nox, noy, noz;
     int nxi, nyi, nzi;
     float best_t;
+    float cull_t; // what node steps cull against: the closest hit among the leaves parked BEFORE the pending one (see RT_DET_CULL)
     int best_rank;
     uint32_t cur;
     uint32_t pend; // speculative traversal: one postponed leaf
@@ -658,6 +680,7 @@ __device__ __forceinline__ void trav_begin(Trav &T, const Ray &r, uint32_t sp0) 
     T.nyi = r.d.y < 0.0f ? 4 : 1;
     T.nzi = r.d.z < 0.0f ? 5 : 2;
     T.best_t = FLT_MAX;
+    T.cull_t = FLT_MAX;
     T.best_rank = RT_NO_HIT;
     T.cur = 0;
     T.pend = RT_REF_NONE;
@@ -669,34 +692,46 @@ __device__ __forceinline__ void trav_begin(Trav &T, const Ray &r, uint32_t sp0) 
 typedef __attribute__((address_space(1))) uint32_t gu32;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// Round record of one pixel slot (see "Rounds" at k_persistent): ten 8-byte granules {value, tag} in five 16-byte
+// Round record of one pixel slot (see "Rounds" at k_persistent): ten 8-byte granules {value, check} in five 16-byte
 // pieces, kRingWords words per slot.  Every piece is written by ONE buffer_store_dwordx4 ... sc1 (write-through: it
-// bypasses the writer's L1 and is dropped from its XCD's L2) and read by ONE buffer_load_dwordx4 ... sc1 (bypasses
-// the reader's L1): the data IS the flag.  This is recipe R2 of cdna_hip_programming.md, Guideline 16 -- naturally
-// aligned 8-byte granules that carry their own tag need no ordering between them, no drain on the writer and no
-// acquire on the reader (MI355X_MICROARCH.md, "Valid forms": observed untorn on gfx950 / ROCm 7.2, "also for 16-B sc1
-// halves"; measured there, not an architectural guarantee -- the assumption this hand-off rests on).  A reader
-// accepts a record only when all ten tags name the (frame, round) it waits for; a record that is half old and half
-// new fails that test and is polled again.  One writer and one reader per record and round, in turn.
+// bypasses the writer's L1 and is dropped from its XCD's L2) and read by ONE buffer_load_dwordx4 ... sc1 (bypasses the
+// reader's L1): the data IS the flag, recipe R2 of cdna_hip_programming.md, Guideline 16 -- no ordering between the
+// pieces, no drain on the writer, one round trip for the reader.
+// A granule's check word is tag ^ rotl(value, 13), tag = frame_id * 64 + round: it names the record's (frame, round)
+// AND is bound to the value beside it.  A reader accepts a record when check ^ rotl(value, 13) == tag in all ten
+// granules.  What that catches, and what is left to assume:
+//   * a record that is part old, part new: the old granules yield an older tag -- polled again;
+//   * a granule whose two words are not from the same store (a 4-byte tear inside an 8-byte granule, which
+//     MI355X_MICROARCH.md reports as never observed on gfx950 / ROCm 7.2 "also for 16-B sc1 halves" but does not
+//     promise): new check with old value yields tag ^ rotl(new ^ old), which is the tag only if the value did not
+//     change (rotl is a bijection) -- DETECTED, exactly, per granule; polled again, and counted when the tag it yields
+//     is one no earlier launch can have written (band_counters[8] -> rt_stats.handoff_torn);
+//   * left: an aligned 4-byte word of an sc1 store is never seen half-written, and an agent-scope sc1 load eventually
+//     observes an sc1 store -- the forms LLVM's gfx942 memory model itself emits for agent-scope relaxed atomics.
+// One writer and one reader per record and round, in turn.  (Two check words in a sixth piece were built first: 2 %
+// of the frame for the extra store, load and registers; binding the tag to the value costs ten rotates a side.)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t ring_rsrc(uint32_t *state, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(state, 0, (int)bytes, 0x00020000);
 }
 #define RT_AUX_SC1 16 /* cache-policy bits of the raw buffer builtins on gfx950: 16 = sc1 */
+__device__ __forceinline__ uint32_t ring_chk(uint32_t v, uint32_t tag) { return tag ^ __builtin_amdgcn_alignbit(v, v, 19); } // tag ^ rotl(v, 13)
 // (The pixel state goes through scalars, not through a reference to the Rng struct: with the struct's address taken
 // here hipcc kept the whole RNG state in scratch memory for the rest of the kernel.)
 __device__ __forceinline__ void ring_publish(uint32_t *state, uint32_t bytes, uint32_t slot, uint32_t tag, uint32_t v0,
                                              uint32_t v1, uint32_t v2, uint32_t v3, uint32_t v4, uint32_t d, V3 col, int k) {
     const __amdgpu_buffer_rsrc_t rs = ring_rsrc(state, bytes);
     const uint32_t off = slot * (uint32_t)(kRingWords * 4);
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{v0, tag, v1, tag}, rs, off, 0, RT_AUX_SC1);
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{v2, tag, v3, tag}, rs, off + 16u, 0, RT_AUX_SC1);
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{v4, tag, d, tag}, rs, off + 32u, 0, RT_AUX_SC1);
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(col.x), tag, __float_as_uint(col.y), tag}, rs, off + 48u, 0, RT_AUX_SC1);
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(col.z), tag, (uint32_t)k, tag}, rs, off + 64u, 0, RT_AUX_SC1);
+    const uint32_t cx = __float_as_uint(col.x), cy = __float_as_uint(col.y), cz = __float_as_uint(col.z), kk = (uint32_t)k;
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{v0, ring_chk(v0, tag), v1, ring_chk(v1, tag)}, rs, off, 0, RT_AUX_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{v2, ring_chk(v2, tag), v3, ring_chk(v3, tag)}, rs, off + 16u, 0, RT_AUX_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{v4, ring_chk(v4, tag), d, ring_chk(d, tag)}, rs, off + 32u, 0, RT_AUX_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{cx, ring_chk(cx, tag), cy, ring_chk(cy, tag)}, rs, off + 48u, 0, RT_AUX_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{cz, ring_chk(cz, tag), kk, ring_chk(kk, tag)}, rs, off + 64u, 0, RT_AUX_SC1);
 }
-// one poll: five loads in flight together, one round trip; true when every granule carries `tag`, and then w[0..9] =
-// the ten values (RNG v0..v4, d; sum x, y, z; sample count)
-__device__ __forceinline__ bool ring_poll(uint32_t *state, uint32_t bytes, uint32_t slot, uint32_t tag, uint32_t (&w)[10]) {
+// one poll: five loads in flight together, one round trip.  true when every granule yields `tag`, and then w[0..9] =
+// the ten values (RNG v0..v4, d; sum x, y, z; sample count).  `beyond` = some granule yielded a tag above `tag`: no
+// launch before this one can have written that (frame ids only grow on a record array), so it is a torn granule.
+__device__ __forceinline__ bool ring_poll(uint32_t *state, uint32_t bytes, uint32_t slot, uint32_t tag, uint32_t (&w)[10], bool &beyond) {
     const __amdgpu_buffer_rsrc_t rs = ring_rsrc(state, bytes);
     const uint32_t off = slot * (uint32_t)(kRingWords * 4);
     asm volatile("" ::: "memory"); // a poll is a fresh read every time: nothing of an earlier one may be reused
@@ -707,8 +742,14 @@ __device__ __forceinline__ bool ring_poll(uint32_t *state, uint32_t bytes, uint3
     const u32x4 e = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 64u, 0, RT_AUX_SC1);
     asm volatile("" ::: "memory");
     w[0] = a.x, w[1] = a.z, w[2] = b.x, w[3] = b.z, w[4] = c.x, w[5] = c.z, w[6] = d.x, w[7] = d.z, w[8] = e.x, w[9] = e.z;
-    return ((a.y ^ tag) | (a.w ^ tag) | (b.y ^ tag) | (b.w ^ tag) | (c.y ^ tag) | (c.w ^ tag) | (d.y ^ tag) | (d.w ^ tag) |
-            (e.y ^ tag) | (e.w ^ tag)) == 0u;
+    // the tag each granule yields: check ^ rotl(value, 13)
+    const uint32_t t0 = ring_chk(a.x, a.y), t1 = ring_chk(a.z, a.w), t2 = ring_chk(b.x, b.y), t3 = ring_chk(b.z, b.w),
+                   t4 = ring_chk(c.x, c.y), t5 = ring_chk(c.z, c.w), t6 = ring_chk(d.x, d.y), t7 = ring_chk(d.z, d.w),
+                   t8 = ring_chk(e.x, e.y), t9 = ring_chk(e.z, e.w);
+    const uint32_t lo = min(min(min(t0, t1), min(t2, t3)), min(min(t4, t5), min(min(t6, t7), min(t8, t9))));
+    const uint32_t hi = max(max(max(t0, t1), max(t2, t3)), max(max(t4, t5), max(max(t6, t7), max(t8, t9))));
+    beyond = hi > tag;
+    return lo == tag && hi == tag;
 }
 
 // LDS through address-space-3 pointers and byte offsets: ds_read / ds_write with the offset in one register
@@ -809,7 +850,7 @@ __device__ __forceinline__ uint32_t pop_or_none(const StackRef &K, uint32_t &sp)
 // one wide node: tests its four child boxes, sets T.cur to the nearest hit child (pushing the others) or to the
 // next stack entry (RT_REF_NONE when the stack is empty).
 // FMT 0: 128-byte float nodes (WideNode).  FMT 1: 64-byte quantized nodes (QuantNode).
-template <int FMT>
+template <int FMT, bool DET>
 __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const StackRef &K) {
     // every stack entry this step can touch is in LDS (entries [e - 1, e + 2] for a stack of e): the common case
     const bool fast = T.sp < K.fast_limit;
@@ -826,7 +867,7 @@ __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const S
         float tn = fmaxf(fmaxf(__builtin_fmaf(nx.C, T.idx, T.nox), __builtin_fmaf(ny.C, T.idy, T.noy)),                \
                          fmaxf(__builtin_fmaf(nz.C, T.idz, T.noz), 0.001f));                                           \
         float tf = fminf(fminf(__builtin_fmaf(fx.C, T.idx, T.nox), __builtin_fmaf(fy.C, T.idy, T.noy)),                \
-                         fminf(__builtin_fmaf(fz.C, T.idz, T.noz), T.best_t));                                         \
+                         fminf(__builtin_fmaf(fz.C, T.idz, T.noz), RT_CULL_T(T)));                                         \
         K_ = (tn <= tf) ? RT_KEY(tn, I) : 0xFFFFFFFFu;                                                                 \
     }
             RT_SLAB(k0, x, 0u)
@@ -865,7 +906,7 @@ __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const S
         float tn = fmaxf(fmaxf(__builtin_fmaf(RT_QB(nqx, SH), sx, ax), __builtin_fmaf(RT_QB(nqy, SH), sy, ay)),        \
                          fmaxf(__builtin_fmaf(RT_QB(nqz, SH), sz, az), 0.001f));                                       \
         float tf = fminf(fminf(__builtin_fmaf(RT_QB(fqx, SH), sx, ax), __builtin_fmaf(RT_QB(fqy, SH), sy, ay)),        \
-                         fminf(__builtin_fmaf(RT_QB(fqz, SH), sz, az), T.best_t));                                     \
+                         fminf(__builtin_fmaf(RT_QB(fqz, SH), sz, az), RT_CULL_T(T)));                                     \
         K_ = (tn <= tf) ? RT_KEY(tn, I) : 0xFFFFFFFFu;                                                                 \
     }
             RT_SLABQ(k0, 0, 0u)
@@ -1007,10 +1048,12 @@ __device__ __forceinline__ void leaf_fire(Trav &T, const KernelScene &S, const R
 // one traversal step: one wide node, or one leaf.  returns false when the ray is finished.
 template <int FMT>
 __device__ __forceinline__ bool trav_step(Trav &T, const KernelScene &S, const Ray &r, const StackRef &K) {
+    constexpr bool DET = true; // leaves are tested where they are reached: the value culled against is always current
     if (!(T.cur & kLeafBit)) {
-        node_step<FMT>(T, S, K);
+        node_step<FMT, DET>(T, S, K);
     } else {
         leaf_test(T, S, r, T.cur);
+        RT_CULL_SYNC(T);
         T.cur = pop_or_none(K, T.sp);
     }
     return T.cur != RT_REF_NONE;
@@ -1110,7 +1153,7 @@ struct PersistArgs {
     int rounds;            // 1 = off
     int round_end[64];     // sample count at which round r hands the pixel on (the last one: ns)
     uint32_t chunk;        // slots a wave takes per atomic on its band counter (64 when rounds > 1)
-    uint32_t *round_state; // kRingWords words per slot: ten {value, tag} granules, tag = frame_id * 64 + the round the record starts
+    uint32_t *round_state; // kRingWords words per slot: ten {value, check} granules, check = tag ^ rotl(value, 13), tag = frame_id * 64 + the round the record starts
     uint32_t round_bytes;  // size of that array (the buffer descriptor's range)
     uint32_t frame_id;
 };
@@ -1126,7 +1169,7 @@ struct PersistArgs {
 // ns/R samples.  A record has one writer and one reader per round, in turn, so one record per slot is enough; its
 // tags name the round it holds (frame_id * 64 + round).  A lane whose record is not there yet keeps the slot and
 // polls; the writer never waits for anything, so this cannot deadlock.  Who runs which samples cannot change a value.
-// Hand-off between lanes of different CUs / XCDs: self-tagged 8-byte granules, written and read sc1 (RingRec above).
+// Hand-off between lanes of different CUs / XCDs: self-tagged, self-checked 8-byte granules, written and read sc1 (ring_publish above).
 // The writer does not wait for its stores and the reader needs one round trip, where a separate flag word needed a
 // drain (s_waitcnt vmcnt(0), which also waits for every load the wave has in flight) before the flag store and a
 // second, dependent round trip after the poll.
@@ -1154,7 +1197,7 @@ struct KArgs { // k_persistent's arguments as they lie in the kernel-argument se
 };
 typedef __attribute__((address_space(4))) const KArgs CKArgs;
 
-template <int MODE, int FMT, int SPEC, int OCC, bool TEX>
+template <int MODE, int FMT, int SPEC, int OCC, bool TEX, bool DET>
 __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFrame F, PersistArgs P, float *fb, int32_t *ids,
                                                    float *ts) {
     const uint32_t lane = threadIdx.x;
@@ -1303,7 +1346,10 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
             }
             if (ring_on && waiting) { // has the previous round's lane published it yet?
                 uint32_t w[10];
-                if (ring_poll(RP.round_state, RP.round_bytes, slot_round & 0x3FFFFFFu, RP.frame_id * 64u + (slot_round >> 26), w)) {
+                bool beyond;
+                const bool got_record = ring_poll(RP.round_state, RP.round_bytes, slot_round & 0x3FFFFFFu, RP.frame_id * 64u + (slot_round >> 26), w, beyond);
+                if (__builtin_expect(beyond, 0)) atomicAdd(&RP.band_counters[kTornCounter], 1u); // a torn granule: counted, polled again
+                if (got_record) {
                     g.v0 = w[0], g.v1 = w[1], g.v2 = w[2], g.v3 = w[3], g.v4 = w[4], g.d = w[5];
                     col = mk(__uint_as_float(w[6]), __uint_as_float(w[7]), __uint_as_float(w[8]));
                     k = (int)w[9];
@@ -1399,7 +1445,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                 // a stack that starts the step below fast_limit ends it at most three entries higher: the pop of the
                 // leaf parking below finds its entry in LDS too
                 const bool lds_only = T.sp < K.fast_limit;
-                if (!(T.cur & kLeafBit)) node_step<FMT>(T, S, K);
+                if (!(T.cur & kLeafBit)) node_step<FMT, DET>(T, S, K);
 #ifdef RT_TRAV_STATS
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the step's stack reads have come back
                 RT_STAT(kStatNodeClocks, __builtin_readcyclecounter() - clk_n0);
@@ -1407,6 +1453,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                 // park a reached leaf in the pending slot and go on with the next stack entry
                 if (T.pend == RT_REF_NONE && T.cur != RT_REF_NONE && (T.cur & kLeafBit)) {
                     T.pend = T.cur;
+                    RT_CULL_SYNC(T); // every leaf parked before this one has been tested by now
                     if (__builtin_expect(lds_only, 1)) {
                         if (T.sp == K.sp0) {
                             T.cur = RT_REF_NONE;
@@ -1480,7 +1527,7 @@ struct QueueArgs {
     float *ts;
     unsigned long long *ray_counter;
 };
-template <int FMT>
+template <int FMT, bool DET>
 __global__ void __launch_bounds__(64, 6) k_trace_queue(KernelScene S, PersistArgs P, QueueArgs Q) {
     const uint32_t lane = threadIdx.x;
     StackRef K;
@@ -1532,9 +1579,10 @@ __global__ void __launch_bounds__(64, 6) k_trace_queue(KernelScene S, PersistArg
             const unsigned long long act = ballot(tracing);
             if (act == 0ull) break;
             if (!exhausted && (int)__popcll(act) < P.threshold) break;
-            if (tracing && !(T.cur & kLeafBit)) node_step<FMT>(T, S, K);
+            if (tracing && !(T.cur & kLeafBit)) node_step<FMT, DET>(T, S, K);
             if (tracing && T.pend == RT_REF_NONE && T.cur != RT_REF_NONE && (T.cur & kLeafBit)) {
                 T.pend = T.cur;
+                    RT_CULL_SYNC(T); // every leaf parked before this one has been tested by now
                 T.cur = pop_or_none(K, T.sp);
             }
             const bool want_leaf = tracing && T.pend != RT_REF_NONE;
@@ -1614,6 +1662,7 @@ struct DualArgs {
 
 template <int FMT, int OCC>
 __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, PersistArgs P, DualArgs D, float *fb) {
+    constexpr bool DET = true;
     const uint32_t lane = threadIdx.x;
     StackRef K;
     stack_ref_init(K, lane, P.spill, P.lds_entries, P.total_lanes);
@@ -1759,9 +1808,10 @@ __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, 
                 RT_STAT(kStatStalledLanes, __popcll(ballot(tracing && T.cur != RT_REF_NONE && (T.cur & kLeafBit) && T.pend != RT_REF_NONE)));
             }
 #endif
-            if (tracing && !(T.cur & kLeafBit)) node_step<FMT>(T, S, K);
+            if (tracing && !(T.cur & kLeafBit)) node_step<FMT, DET>(T, S, K);
             if (tracing && T.pend == RT_REF_NONE && T.cur != RT_REF_NONE && (T.cur & kLeafBit)) {
                 T.pend = T.cur;
+                    RT_CULL_SYNC(T); // every leaf parked before this one has been tested by now
                 T.cur = pop_or_none(K, T.sp);
             }
             const bool want_leaf = tracing && T.pend != RT_REF_NONE;
@@ -1858,9 +1908,11 @@ hipError_t launch_trace_queue(const KernelScene &S, const PersistLaunch &L, cons
     Q.ray_counter = ray_counter;
     const uint32_t waves = std::min<uint32_t>((uint32_t)L.grid_waves, (n + 63u) / 64u);
     if (L.node_format == 0)
-        hipLaunchKernelGGL((k_trace_queue<0>), dim3(waves), dim3(64), lds, stream, S, P, Q);
+        hipLaunchKernelGGL((k_trace_queue<0, true>), dim3(waves), dim3(64), lds, stream, S, P, Q);
+    else if (L.deterministic)
+        hipLaunchKernelGGL((k_trace_queue<1, true>), dim3(waves), dim3(64), lds, stream, S, P, Q);
     else
-        hipLaunchKernelGGL((k_trace_queue<1>), dim3(waves), dim3(64), lds, stream, S, P, Q);
+        hipLaunchKernelGGL((k_trace_queue<1, false>), dim3(waves), dim3(64), lds, stream, S, P, Q);
     return hipGetLastError();
 }
 
@@ -1918,36 +1970,53 @@ hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &
             hipLaunchKernelGGL((k_dual<1, 4>), grid, block, lds, stream, S, F, P, D, fb);
         return hipGetLastError();
     }
+    // DET 0 (cull against the freshest hit, results timing-dependent on ~10^-10 of rays) exists only where it differs:
+    // speculative traversal over quantised nodes
+    const bool det = L.deterministic || !L.speculative || L.node_format == 0;
     if (mode == 0 && S.uv != nullptr) { // textured scene: the instances with the texture path, 128 VGPRs (4 waves/SIMD)
         if (L.node_format == 0 && !L.speculative)
-            hipLaunchKernelGGL((k_persistent<0, 0, 0, 4, true>), grid, block, lds, stream, S, F, P, fb, ids, ts);
+            hipLaunchKernelGGL((k_persistent<0, 0, 0, 4, true, true>), grid, block, lds, stream, S, F, P, fb, ids, ts);
         else if (L.node_format == 0)
-            hipLaunchKernelGGL((k_persistent<0, 0, 1, 4, true>), grid, block, lds, stream, S, F, P, fb, ids, ts);
+            hipLaunchKernelGGL((k_persistent<0, 0, 1, 4, true, true>), grid, block, lds, stream, S, F, P, fb, ids, ts);
         else if (!L.speculative)
-            hipLaunchKernelGGL((k_persistent<0, 1, 0, 4, true>), grid, block, lds, stream, S, F, P, fb, ids, ts);
+            hipLaunchKernelGGL((k_persistent<0, 1, 0, 4, true, true>), grid, block, lds, stream, S, F, P, fb, ids, ts);
+        else if (det)
+            hipLaunchKernelGGL((k_persistent<0, 1, 1, 4, true, true>), grid, block, lds, stream, S, F, P, fb, ids, ts);
         else
-            hipLaunchKernelGGL((k_persistent<0, 1, 1, 4, true>), grid, block, lds, stream, S, F, P, fb, ids, ts);
+            hipLaunchKernelGGL((k_persistent<0, 1, 1, 4, true, false>), grid, block, lds, stream, S, F, P, fb, ids, ts);
         return hipGetLastError();
     }
-#define RT_LAUNCH(M, Fm, Sp, Oc)                                                                                       \
-    hipLaunchKernelGGL((k_persistent<M, Fm, Sp, Oc, false>), grid, block, lds, stream, S, F, P, fb, ids, ts)
-#define RT_LAUNCH_OCC(M, Sp)                                                                                           \
+#define RT_LAUNCH(M, Fm, Sp, Oc, Dt)                                                                                   \
+    hipLaunchKernelGGL((k_persistent<M, Fm, Sp, Oc, false, Dt>), grid, block, lds, stream, S, F, P, fb, ids, ts)
+#define RT_LAUNCH_OCC(M, Sp, Dt)                                                                                       \
     if (L.occupancy >= 8)                                                                                              \
-        RT_LAUNCH(M, 1, Sp, 8);                                                                                        \
+        RT_LAUNCH(M, 1, Sp, 8, Dt);                                                                                    \
     else if (L.occupancy >= 6)                                                                                         \
-        RT_LAUNCH(M, 1, Sp, 6);                                                                                        \
+        RT_LAUNCH(M, 1, Sp, 6, Dt);                                                                                    \
     else                                                                                                               \
-        RT_LAUNCH(M, 1, Sp, 4);
+        RT_LAUNCH(M, 1, Sp, 4, Dt);
     const int sel = (mode ? 4 : 0) | (L.node_format ? 2 : 0) | (L.speculative ? 1 : 0);
     switch (sel) {
-    case 0: RT_LAUNCH(0, 0, 0, 4); break;
-    case 1: RT_LAUNCH(0, 0, 1, 4); break;
-    case 2: RT_LAUNCH_OCC(0, 0) break;
-    case 3: RT_LAUNCH_OCC(0, 1) break;
-    case 4: RT_LAUNCH(1, 0, 0, 4); break;
-    case 5: RT_LAUNCH(1, 0, 1, 4); break;
-    case 6: RT_LAUNCH_OCC(1, 0) break;
-    default: RT_LAUNCH_OCC(1, 1) break;
+    case 0: RT_LAUNCH(0, 0, 0, 4, true); break;
+    case 1: RT_LAUNCH(0, 0, 1, 4, true); break;
+    case 2: RT_LAUNCH_OCC(0, 0, true) break;
+    case 3:
+        if (det) {
+            RT_LAUNCH_OCC(0, 1, true)
+        } else {
+            RT_LAUNCH_OCC(0, 1, false)
+        }
+        break;
+    case 4: RT_LAUNCH(1, 0, 0, 4, true); break;
+    case 5: RT_LAUNCH(1, 0, 1, 4, true); break;
+    case 6: RT_LAUNCH_OCC(1, 0, true) break;
+    default:
+        if (det) {
+            RT_LAUNCH_OCC(1, 1, true)
+        } else {
+            RT_LAUNCH_OCC(1, 1, false)
+        }
+        break;
     }
 #undef RT_LAUNCH_OCC
 #undef RT_LAUNCH

@@ -45,6 +45,7 @@ struct rt_ctx {
     int primary_waves = 16;   // primary rays: persistent waves per CU, at most
     int primary_chunk = 256;  // primary rays: pixel slots per band-counter atomic
     int collapse = 1;         // how binary subtrees become wide nodes (wide_bvh.h)
+    int deterministic = 1;    // RT_OPT_DETERMINISTIC
     // analysis builds: rays recorded by the last render (rt_test_dump_rays)
     float *d_ray_dump = nullptr;
     unsigned long long *d_ray_dump_count = nullptr;
@@ -499,7 +500,7 @@ void fill_stats(rt_ctx *c, rt_stats *st, uint64_t rays, float ms, double total_m
     st->wide_nodes = c->n_wide;
     st->prims = c->n_prims;
     st->stack_entries = c->wide.stack_entries;
-    st->reserved = 0;
+    st->handoff_torn = 0;
 }
 
 // The tag of a round record is frame_id * 64 + round, and a record array is never cleared between frames: that needs
@@ -546,6 +547,7 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_ra
     L.threshold = c->refill_threshold;
     L.node_format = c->node_format;
     L.speculative = c->kernel_variant >= 2 ? 1 : 0;
+    L.deterministic = c->deterministic;
     L.dual = c->kernel_variant == 3 ? 1 : 0;
     L.shade_batch = c->shade_batch;
     L.swap_batch = c->swap_batch;
@@ -981,6 +983,10 @@ int rt_set_option(rt_ctx *c, int option, int64_t value) {
         if (value < 100 || value > 400) return fail(c, RT_E_ARG, "taper 100..400 (percent)");
         c->tail_taper = (int)value;
         return RT_OK;
+    case RT_OPT_DETERMINISTIC:
+        if (value != 0 && value != 1) return fail(c, RT_E_ARG, "deterministic 0 or 1");
+        c->deterministic = (int)value;
+        return RT_OK;
     case RT_OPT_TOPOLOGY:
         if (value != 0 && value != 1) return fail(c, RT_E_ARG, "topology 0 or 1");
         if (c->topology != (int)value) c->scene_on_device = false;
@@ -1013,6 +1019,7 @@ int rt_get_option(rt_ctx *c, int option, int64_t *value) {
     case RT_OPT_TAIL_SPLIT: *value = c->tail_split; return RT_OK;
     case RT_OPT_TAIL_TAPER: *value = c->tail_taper; return RT_OK;
     case RT_OPT_COLLAPSE: *value = c->collapse; return RT_OK;
+    case RT_OPT_DETERMINISTIC: *value = c->deterministic; return RT_OK;
     case RT_OPT_SEED_SALT: *value = (int64_t)c->seed_salt; return RT_OK;
     case RT_OPT_RAW_SUM: *value = c->raw_sum; return RT_OK;
     case RT_OPT_QUEUE_THRESHOLD: *value = c->queue_threshold; return RT_OK;
@@ -1047,6 +1054,11 @@ static int render_into(rt_ctx *c, float *d_fb, rt_stats *st, double t0, bool no_
     unsigned long long rays = 0;
     HIPCHK(c, hipMemcpy(&rays, F.ray_counter, sizeof(rays), hipMemcpyDeviceToHost));
     fill_stats(c, st, rays, ms, now_ms() - t0);
+    if (st && c->kernel_variant >= 1 && L.rounds > 1) { // round records seen torn (detected, polled again): expected 0
+        unsigned int torn = 0;
+        HIPCHK(c, hipMemcpy(&torn, L.band_counters + kTornCounter, sizeof(torn), hipMemcpyDeviceToHost));
+        st->handoff_torn = (int32_t)std::min<unsigned int>(torn, 0x7FFFFFFFu);
+    }
     return RT_OK;
 }
 

@@ -45,6 +45,7 @@ OPT_PRIMARY_WAVES = 22
 OPT_PRIMARY_CHUNK = 23
 OPT_TAIL_TAPER = 24
 OPT_COLLAPSE = 25
+OPT_DETERMINISTIC = 26
 
 
 class RtStats(C.Structure):
@@ -55,7 +56,7 @@ class RtStats(C.Structure):
         ("wide_nodes", C.c_uint64),
         ("prims", C.c_uint64),
         ("stack_entries", C.c_int32),
-        ("reserved", C.c_int32),
+        ("handoff_torn", C.c_int32),
     ]
 
 

@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--tail", type=ints, default=[0])
     ap.add_argument("--taper", type=ints, default=[150])
     ap.add_argument("--collapse", type=ints, default=[1])
+    ap.add_argument("--det", type=int, default=None, help="RT_OPT_DETERMINISTIC (libraries that have the option)")
     ap.add_argument("--pwaves", type=ints, default=[16], help="primary rays: waves per CU")
     ap.add_argument("--pchunk", type=ints, default=[256], help="primary rays: slots per atomic")
     args = ap.parse_args()
@@ -49,6 +50,8 @@ def main():
     eng.setTriangles(tris)
     eng.setMaxDepth(args.depth)
     eng.setCamera(**scenes.BENCH_CAMERA)
+    if args.det is not None:
+        eng.setOption(26, args.det)
     nodes = None
     warmed = False
     for leaf, bm, kv, th, wv, ld, fm, lb, oc, tp, sb, wb, ts, tap, col in itertools.product(args.leaf, args.box_mode, args.kernel, args.threshold, args.waves, args.lds, args.fmt, args.batch, args.occ, args.topo, args.shade, args.swap, args.tail, args.taper, args.collapse):
