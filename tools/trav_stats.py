@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--tail", type=int, default=None)
     ap.add_argument("--pchunk", type=int, default=None)
     ap.add_argument("--pwaves", type=int, default=None)
+    ap.add_argument("--det", type=int, default=None, help="RT_OPT_DETERMINISTIC")
+    ap.add_argument("--fmt", type=int, default=None, help="RT_OPT_NODE_FORMAT")
     ap.add_argument("--primary-only", action="store_true", help="with --wave-times: the primary-ray kernel instead of the render")
     ap.add_argument("--wave-times", action="store_true", help="when each wave of the render ends (share of waves still running over time)")
     ap.add_argument("--queue-waves", type=lambda t: [int(x) for x in t.split(",")], default=[16])
@@ -83,7 +85,8 @@ def main():
         eng.setOption(E.OPT_LEAF_SIZE, args.leaf)
     for opt, v in ((E.OPT_KERNEL, args.kernel), (E.OPT_SHADE_BATCH, args.shade), (E.OPT_SWAP_BATCH, args.swap),
                    (E.OPT_OCCUPANCY, args.occ), (E.OPT_WAVES_PER_CU, args.waves), (E.OPT_TAIL_SPLIT, args.tail),
-                   (E.OPT_PRIMARY_CHUNK, args.pchunk), (E.OPT_PRIMARY_WAVES, args.pwaves)):
+                   (E.OPT_PRIMARY_CHUNK, args.pchunk), (E.OPT_PRIMARY_WAVES, args.pwaves), (E.OPT_DETERMINISTIC, args.det),
+                   (E.OPT_NODE_FORMAT, args.fmt)):
         if v is not None:
             eng.setOption(opt, v)
     eng.setTriangles(scenes.heightfield(args.grid))
