@@ -153,7 +153,10 @@ enum {
     RT_OPT_REFILL_THRESHOLD = 8, /* kernel 1: refill when fewer than this many of 64 lanes still traverse */
     RT_OPT_WAVES_PER_CU = 9,     /* kernel 1: persistent waves launched per CU */
     RT_OPT_LDS_STACK = 10,       /* kernel 1: stack entries per lane kept in LDS (the rest spill to HBM) */
-    RT_OPT_NODE_FORMAT = 11,     /* kernel 1/2: 0 = 128-byte float nodes, 1 = 64-byte quantized nodes (default) */
+    RT_OPT_NODE_FORMAT = 11,     /* kernel 1/2: 0 = 128-byte float nodes, 1 = 64-byte quantized nodes (default),
+                                  * 2 (kernel 2 only) = the packed scene: 48-byte nodes and the primitives in one record
+                                  * array, three loads per node visit instead of four; a tree that does not fit it
+                                  * (leaves of more than two primitives, 4 GiB or more) and an imported scene run 1 */
     RT_OPT_LEAF_BATCH = 12,      /* kernel 2: primitive tests run when this many lanes have a leaf pending */
     RT_OPT_OCCUPANCY = 13,       /* kernel 1/2, quantized nodes: waves per SIMD the registers are held to: 4, 6, 8 */
     RT_OPT_TOPOLOGY = 14,        /* device hierarchy: 0 = the reference's tree, wide-ified; 1 = a binned-SAH tree
@@ -237,6 +240,12 @@ int rt_test_build_bvh(const rt_triangle148 *tris, int n, int64_t rand_calls_befo
  * depth, stack_entries}.  topology: bit 0 = RT_OPT_TOPOLOGY, bit 1 = RT_OPT_COLLAPSE. */
 int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size,
                         int box_mode, int topology, void *wide_nodes, void *quant_nodes, void *prims, int32_t info[4]);
+
+/* The packed scene of RT_OPT_NODE_FORMAT 2 alone (no GPU needed; box mode 0).  Sizes first (NULL buffers): info[0] =
+ * records (0: the tree does not fit the format, e.g. leaves of more than two primitives), info[1] = wide nodes among
+ * them.  records: 48 bytes each; rec_of_prim[p] = record of primitive p of rt_test_wide_layout's prims. */
+int rt_test_pack_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size, int topology,
+                        void *records, uint32_t *rec_of_prim, int64_t info[2]);
 
 /* rt_export_scene's block from records and nodes alone, and a block's header (no GPU needed): info = {wide nodes,
  * primitives, uv records, float nodes, binary nodes, total bytes, depth, stack entries, then the byte offsets of the

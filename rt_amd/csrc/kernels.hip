@@ -86,8 +86,12 @@ struct Hit {
 struct PrimRegs {
     float4 A, B, C;
 };
+// PSTR: float4s per index step.  3 = `rank` counts 48-byte records (formats 0 and 1, and everything outside the
+// traversal); 1 = `rank` is a unit address of the packed scene (format 2, rt_types.h), below 2^28: a 32-bit byte offset.
+template <int PSTR = 3>
 __device__ __forceinline__ PrimRegs prim_load(const float4 *__restrict__ prims, uint32_t rank) {
-    const float4 *p = prims + 3 * (size_t)rank;
+    const float4 *p = PSTR == 1 ? reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(prims) + (size_t)(uint32_t)(rank << 4))
+                                : prims + 3 * (size_t)rank;
     PrimRegs R;
     R.A = p[0], R.B = p[1], R.C = p[2];
     // The test reads C.x, C.y and C.w, and hipcc narrows the third load to a dwordx2 plus a dword: FOUR vector-memory
@@ -135,15 +139,17 @@ __device__ __forceinline__ bool prim_test(const PrimRegs &R, const Ray &r, float
 
 // min t; ties go to the earlier DFS leaf of the REFERENCE tree (pbrt_engine.cu:421-438).  The tie branch is rare:
 // it re-reads the incumbent's reference rank instead of carrying it in a register.
+template <int PSTR = 3>
 __device__ __forceinline__ bool better_hit(const float4 *__restrict__ prims, float t, int ref_rank, float best_t, int best_idx) {
     if (t < best_t) return true;
-    if (t == best_t && best_idx != RT_NO_HIT) return ref_rank < __float_as_int(prims[3 * (size_t)best_idx + 2].w);
+    if (t == best_t && best_idx != RT_NO_HIT) return ref_rank < __float_as_int(prims[PSTR * (size_t)best_idx + 2].w);
     return false;
 }
 
+template <int PSTR = 3>
 __device__ __forceinline__ bool prim_test(const float4 *__restrict__ prims, uint32_t rank, const Ray &r, float &t_out,
                                           int &ref_rank) {
-    return prim_test(prim_load(prims, rank), r, t_out, ref_rank);
+    return prim_test(prim_load<PSTR>(prims, rank), r, t_out, ref_rank);
 }
 
 __device__ __forceinline__ float safe_inv(float d) {
@@ -653,6 +659,23 @@ __global__ void __launch_bounds__(64) k_render(KernelScene S, KernelFrame F, flo
 // (a template flag, DET, on the traversal code: RT_OPT_DETERMINISTIC 0 runs the instances without it, which cull against
 // the freshest value and take 5 % less time on the bench frame -- 37.0 against 39.0 ms -- at the price of that timing
 // dependence.  The non-speculative and float-node variants always cull deterministically.)
+// Child references by node format (rt_types.h).  Formats 0 and 1: leaf bit 31, count - 1 in bits 30:28, first
+// primitive (a record index) below.  Format 2 (packed scene): unit << 2 | leaf << 1 | (count - 1); a leaf's primitives
+// are the records at units first, first + 3, ...; T.best_rank holds a UNIT address while a ray is traced and becomes a
+// record index (unit / 3) when the ray is finished (hit_record_index).  RT_REF_NONE has the leaf bit of either.
+template <int FMT> __device__ __forceinline__ bool ref_is_leaf(uint32_t r) { return FMT == 2 ? (r & kPackLeafBit) != 0u : (r & kLeafBit) != 0u; }
+template <int FMT> __device__ __forceinline__ uint32_t leaf_first(uint32_t r) { return FMT == 2 ? r >> 2 : r & kLeafStartMask; }
+template <int FMT> __device__ __forceinline__ uint32_t leaf_count(uint32_t r) { return FMT == 2 ? (r & 1u) + 1u : ((r >> 28) & 7u) + 1u; }
+template <int FMT> __device__ __forceinline__ bool leaf_has_second(uint32_t r) { return FMT == 2 ? (r & 1u) != 0u : (r & 0x70000000u) != 0u; }
+template <int FMT> struct PrimIndex {
+    static constexpr int stride = FMT == 2 ? 1 : 3; // float4s per index step (prim_load's PSTR)
+    static constexpr uint32_t next = FMT == 2 ? 3u : 1u; // index step from one primitive of a leaf to the next
+};
+template <int FMT> __device__ __forceinline__ int hit_record_index(int best_rank) {
+    if (FMT != 2 || best_rank == RT_NO_HIT) return best_rank;
+    return (int)(__umulhi((uint32_t)best_rank, 0xAAAAAAABu) >> 1); // unit / 3, exact below 2^31
+}
+
 #define RT_CULL_T(T) (DET ? (T).cull_t : (T).best_t)
 #define RT_CULL_SYNC(T)                                                                                                \
     do {                                                                                                               \
@@ -810,19 +833,30 @@ __device__ __forceinline__ uint32_t child_ref(uint32_t key, uint32_t child16) {
     return *(lu32 *)(uintptr_t)a;
 }
 
+// packed scene: reference of the child whose slot * 8 sits in the key's low five bits
+__device__ __forceinline__ uint32_t pack_ref(uint32_t child_bytes, uint32_t base4, uint32_t key) {
+    uint32_t b;
+    asm("v_bfe_u32 %0, %1, %2, 8" : "=v"(b) : "v"(child_bytes), "v"(key));
+    return base4 + b;
+}
+
 // sort the (up to four) hit children by entry distance, continue with the nearest, push the others far-first
-#define RT_SORT_AND_PUSH()                                                                                             \
+// PREP: statement that makes the references available; REF(key): the reference of the child a sort key names
+#define RT_REFS_TO_LDS                                                                                                 \
+    const uint32_t lane16 = K.child16;                                                                                 \
+    *(lu128 *)(uintptr_t)lane16 = u32x4{ch.x, ch.y, ch.z, ch.w};
+#define RT_REF_FROM_LDS(KEY) child_ref(KEY, lane16)
+#define RT_SORT_AND_PUSH(PREP, REF)                                                                                    \
     RT_CSWAP(k0, k1)                                                                                                   \
     RT_CSWAP(k2, k3)                                                                                                   \
     RT_CSWAP(k0, k2)                                                                                                   \
     RT_CSWAP(k1, k3)                                                                                                   \
     RT_CSWAP(k1, k2)                                                                                                   \
     if (k0 != 0xFFFFFFFFu) {                                                                                           \
-        const uint32_t lane16 = K.child16;                                                                             \
-        *(lu128 *)(uintptr_t)lane16 = u32x4{ch.x, ch.y, ch.z, ch.w};                                                   \
-        T.cur = child_ref(k0, lane16);                                                                                 \
+        PREP                                                                                                           \
+        T.cur = REF(k0);                                                                                               \
         if (k1 != 0xFFFFFFFFu) {                                                                                       \
-            const uint32_t c1 = child_ref(k1, lane16), c2 = child_ref(k2, lane16), c3 = child_ref(k3, lane16);         \
+            const uint32_t c1 = REF(k1), c2 = REF(k2), c3 = REF(k3);                                                   \
             if (__builtin_expect(fast, 1)) { /* all three entries would be in LDS */                                   \
                 if (k2 != 0xFFFFFFFFu) {                                                                               \
                     if (k3 != 0xFFFFFFFFu) {                                                                           \
@@ -875,8 +909,8 @@ __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const S
             RT_SLAB(k2, z, 2u)
             RT_SLAB(k3, w, 3u)
 #undef RT_SLAB
-            RT_SORT_AND_PUSH()
-        } else {
+            RT_SORT_AND_PUSH(RT_REFS_TO_LDS, RT_REF_FROM_LDS)
+        } else if (FMT == 1) {
             // byte offset in 32 bits (rt_abi.cpp refuses more than 2^26 wide nodes): one shift and the scalar-base form
             // of global_load instead of a 64-bit shift and a 64-bit add
             const uint4 *n = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(S.qnodes) + (size_t)(uint32_t)(T.cur << 6));
@@ -901,22 +935,51 @@ __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const S
             // spills: 56.2 vs 53.2 ms.  With the child references in LDS the pairs fit -- 84 instead of 96 vector
             // instructions in this block, no spill in the loop -- and the frame still took 47.0 vs 45.25 ms: a packed
             // FMA does not issue at the rate of a plain one here.)
-#define RT_SLABQ(K_, SH, I)                                                                                            \
+#define RT_SLABQ(K_, SH, I, KEYF)                                                                                         \
     {                                                                                                                  \
         float tn = fmaxf(fmaxf(__builtin_fmaf(RT_QB(nqx, SH), sx, ax), __builtin_fmaf(RT_QB(nqy, SH), sy, ay)),        \
                          fmaxf(__builtin_fmaf(RT_QB(nqz, SH), sz, az), 0.001f));                                       \
         float tf = fminf(fminf(__builtin_fmaf(RT_QB(fqx, SH), sx, ax), __builtin_fmaf(RT_QB(fqy, SH), sy, ay)),        \
                          fminf(__builtin_fmaf(RT_QB(fqz, SH), sz, az), RT_CULL_T(T)));                                     \
-        K_ = (tn <= tf) ? RT_KEY(tn, I) : 0xFFFFFFFFu;                                                                 \
+        K_ = (tn <= tf) ? KEYF(tn, I) : 0xFFFFFFFFu;                                                                   \
     }
-            RT_SLABQ(k0, 0, 0u)
-            RT_SLABQ(k1, 8, 1u)
-            RT_SLABQ(k2, 16, 2u)
-            RT_SLABQ(k3, 24, 3u)
+            RT_SLABQ(k0, 0, 0u, RT_KEY)
+            RT_SLABQ(k1, 8, 1u, RT_KEY)
+            RT_SLABQ(k2, 16, 2u, RT_KEY)
+            RT_SLABQ(k3, 24, 3u, RT_KEY)
+            RT_SORT_AND_PUSH(RT_REFS_TO_LDS, RT_REF_FROM_LDS)
+        } else {
+            // packed scene: three loads; a reference is the byte offset of its record / 4 (below 2^30)
+            const uint4 *n = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(S.qnodes) + (size_t)(uint32_t)(T.cur << 2));
+            uint4 h = n[0], qa = n[1], qb = n[2];
+            RT_PIN4(h);
+            RT_PIN4(qa);
+            RT_PIN4(qb);
+            // grid step per axis = 2^(exponent byte), folded into the ray's reciprocal direction
+            const float sx = __builtin_ldexpf(T.idx, __builtin_amdgcn_sbfe((int)qb.w, 0, 8));
+            const float sy = __builtin_ldexpf(T.idy, __builtin_amdgcn_sbfe((int)qb.w, 8, 8));
+            const float sz = __builtin_ldexpf(T.idz, __builtin_amdgcn_sbfe((int)qb.w, 16, 8));
+            const float ax = __builtin_fmaf(__uint_as_float(h.x), T.idx, T.nox);
+            const float ay = __builtin_fmaf(__uint_as_float(h.y), T.idy, T.noy);
+            const float az = __builtin_fmaf(__uint_as_float(h.z), T.idz, T.noz);
+            const bool ngx = T.nxi != 0, ngy = T.nyi != 1, ngz = T.nzi != 2;
+            const uint32_t nqx = ngx ? qa.y : qa.x, fqx = ngx ? qa.x : qa.y;
+            const uint32_t nqy = ngy ? qa.w : qa.z, fqy = ngy ? qa.z : qa.w;
+            const uint32_t nqz = ngz ? qb.y : qb.x, fqz = ngz ? qb.x : qb.y;
+            // the sort key carries 8 * slot in its low five bits: v_bfe_u32 takes the child's byte by it (the
+            // instruction reads bits 4:0 of the offset operand), one add makes the reference
+#define RT_KEY_PACKED(TN, I) ((__float_as_uint(TN) & ~31u) | ((I) << 3))
+            RT_SLABQ(k0, 0, 0u, RT_KEY_PACKED)
+            RT_SLABQ(k1, 8, 1u, RT_KEY_PACKED)
+            RT_SLABQ(k2, 16, 2u, RT_KEY_PACKED)
+            RT_SLABQ(k3, 24, 3u, RT_KEY_PACKED)
+#undef RT_KEY_PACKED
+#define RT_REF_PACKED(KEY) pack_ref(h.w, qb.z, KEY)
+            RT_SORT_AND_PUSH(, RT_REF_PACKED)
+#undef RT_REF_PACKED
+        }
 #undef RT_SLABQ
 #undef RT_QB
-            RT_SORT_AND_PUSH()
-        }
     }
     if (__builtin_expect(fast, 1)) {
         if (T.sp == K.sp0) {
@@ -931,18 +994,20 @@ __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const S
 }
 
 // one leaf: tests its primitives; min t, ties to the earlier DFS leaf (pbrt_engine.cu:421-438)
+template <int FMT>
 __device__ __forceinline__ void leaf_test(Trav &T, const KernelScene &S, const Ray &r, uint32_t ref) {
-    const uint32_t start = ref & kLeafStartMask;
-    const uint32_t cnt = ((ref >> 28) & 7u) + 1u;
+    constexpr int PS = PrimIndex<FMT>::stride;
+    const uint32_t start = leaf_first<FMT>(ref);
+    const uint32_t end = start + leaf_count<FMT>(ref) * PrimIndex<FMT>::next;
     // (loading two primitives per trip before testing the first hides the second round trip of a two-primitive leaf,
     // and costs 26 more spilled registers in the refill phase: 48.4 vs 48.2 ms, dropped)
-    for (uint32_t i = 0; i < cnt; i++) {
+    for (uint32_t p = start; p != end; p += PrimIndex<FMT>::next) {
         float t;
         int rr;
-        if (prim_test(S.prims, start + i, r, t, rr)) {
-            if (better_hit(S.prims, t, rr, T.best_t, T.best_rank)) {
+        if (prim_test<PS>(S.prims, p, r, t, rr)) {
+            if (better_hit<PS>(S.prims, t, rr, T.best_t, T.best_rank)) {
                 T.best_t = t;
-                T.best_rank = (int)(start + i);
+                T.best_rank = (int)p;
             }
         }
     }
@@ -965,12 +1030,15 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) {
 // LDS traffic and ~25.  Owners without a helper, and primitives beyond the second, take the loop.
 // Must be called by all 64 lanes.  xchg = LDS address of s_child (the leaf exchange's fields).
 // leaf_mask = ballot(want_leaf), which the caller has.
+template <int FMT>
 __device__ __forceinline__ void leaf_fire(Trav &T, const KernelScene &S, const Ray &cur, bool want_leaf,
                                           unsigned long long leaf_mask, uint32_t xchg) {
+    constexpr int PS = PrimIndex<FMT>::stride;
+    constexpr uint32_t PN = PrimIndex<FMT>::next;
     const uint32_t ref = T.pend;
-    const uint32_t start = ref & kLeafStartMask;
+    const uint32_t start = leaf_first<FMT>(ref);
     // masks stay scalar: owners = lanes whose leaf holds a second primitive, free = lanes without a leaf
-    const bool has2 = (ref & 0x70000000u) != 0u, two = has2 && want_leaf;
+    const bool has2 = leaf_has_second<FMT>(ref), two = has2 && want_leaf;
     const unsigned long long own_m = ballot(has2) & leaf_mask, free_m = ~leaf_mask;
     const uint32_t n_own = (uint32_t)__popcll(own_m), n_free = (uint32_t)__popcll(free_m);
     const uint32_t pairs = n_own < n_free ? n_own : n_free; // wave-uniform
@@ -985,7 +1053,7 @@ __device__ __forceinline__ void leaf_fire(Trav &T, const KernelScene &S, const R
             *(lu32 *)(uintptr_t)(slot + 3u * 256u) = __float_as_uint(cur.d.x);
             *(lu32 *)(uintptr_t)(slot + 4u * 256u) = __float_as_uint(cur.d.y);
             *(lu32 *)(uintptr_t)(slot + 5u * 256u) = __float_as_uint(cur.d.z);
-            *(lu32 *)(uintptr_t)(slot + 6u * 256u) = start + 1u;
+            *(lu32 *)(uintptr_t)(slot + 6u * 256u) = start + PN;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1006,7 +1074,7 @@ __device__ __forceinline__ void leaf_fire(Trav &T, const KernelScene &S, const R
     float t = FLT_MAX;
     int rr = 0;
     bool hit = false;
-    if (want_leaf || helping) hit = prim_test(S.prims, lp, lr, t, rr);
+    if (want_leaf || helping) hit = prim_test<PS>(S.prims, lp, lr, t, rr);
     if (pairs != 0u) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1018,26 +1086,26 @@ __device__ __forceinline__ void leaf_fire(Trav &T, const KernelScene &S, const R
         __builtin_amdgcn_wave_barrier();
     }
     if (want_leaf) {
-        if (hit && better_hit(S.prims, t, rr, T.best_t, T.best_rank)) {
+        if (hit && better_hit<PS>(S.prims, t, rr, T.best_t, T.best_rank)) {
             T.best_t = t;
             T.best_rank = (int)start;
         }
-        const uint32_t cnt = ((ref >> 28) & 7u) + 1u;
-        uint32_t i = 1u;
+        const uint32_t end = start + leaf_count<FMT>(ref) * PN;
+        uint32_t p = start + PN;
         if (exporting) {
             const float t1 = __uint_as_float(*(lu32 *)(uintptr_t)(slot + 0u * 256u));
             const int rr1 = (int)*(lu32 *)(uintptr_t)(slot + 1u * 256u);
-            if (t1 < FLT_MAX && better_hit(S.prims, t1, rr1, T.best_t, T.best_rank)) {
+            if (t1 < FLT_MAX && better_hit<PS>(S.prims, t1, rr1, T.best_t, T.best_rank)) {
                 T.best_t = t1;
-                T.best_rank = (int)(start + 1u);
+                T.best_rank = (int)(start + PN);
             }
-            i = 2u;
+            p += PN;
         }
-        for (; i < cnt; i++) {
-            if (prim_test(S.prims, start + i, cur, t, rr)) {
-                if (better_hit(S.prims, t, rr, T.best_t, T.best_rank)) {
+        for (; p != end; p += PN) {
+            if (prim_test<PS>(S.prims, p, cur, t, rr)) {
+                if (better_hit<PS>(S.prims, t, rr, T.best_t, T.best_rank)) {
                     T.best_t = t;
-                    T.best_rank = (int)(start + i);
+                    T.best_rank = (int)p;
                 }
             }
         }
@@ -1049,10 +1117,10 @@ __device__ __forceinline__ void leaf_fire(Trav &T, const KernelScene &S, const R
 template <int FMT>
 __device__ __forceinline__ bool trav_step(Trav &T, const KernelScene &S, const Ray &r, const StackRef &K) {
     constexpr bool DET = true; // leaves are tested where they are reached: the value culled against is always current
-    if (!(T.cur & kLeafBit)) {
+    if (!ref_is_leaf<FMT>(T.cur)) {
         node_step<FMT, DET>(T, S, K);
     } else {
-        leaf_test(T, S, r, T.cur);
+        leaf_test<FMT>(T, S, r, T.cur);
         RT_CULL_SYNC(T);
         T.cur = pop_or_none(K, T.sp);
     }
@@ -1259,7 +1327,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
             result_ready = false;
             Hit h;
             h.t = T.best_t;
-            h.rank = T.best_rank;
+            h.rank = hit_record_index<FMT>(T.best_rank);
             const size_t pixel_index = (size_t)(pij >> 16) * (size_t)RF.nx + (size_t)(pij & 0xFFFFu);
             if (MODE == 1) {
                 if (h.rank != RT_NO_HIT) {
@@ -1428,15 +1496,15 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
             } else {
 #ifdef RT_TRAV_STATS
                 {
-                    const int nl = __popcll(ballot(tracing && !(T.cur & kLeafBit)));
+                    const int nl = __popcll(ballot(tracing && !ref_is_leaf<FMT>(T.cur)));
                     RT_STAT(kStatNodeLanes, nl);
                     RT_STAT(kStatNodeIters, nl != 0);
                     for (int bb = 0; bb < 8; bb++) { // divergence per bounce: lanes of each bounce depth testing a node
-                        const int nb = __popcll(ballot(tracing && !(T.cur & kLeafBit) && (bounce < 7 ? bounce : 7) == bb));
+                        const int nb = __popcll(ballot(tracing && !ref_is_leaf<FMT>(T.cur) && (bounce < 7 ? bounce : 7) == bb));
                         RT_STAT(kStatNodeLanesByBounce + bb, nb);
                         RT_STAT(kStatItersWithBounce + bb, nb != 0);
                     }
-                    RT_STAT(kStatStalledLanes, __popcll(ballot(tracing && T.cur != RT_REF_NONE && (T.cur & kLeafBit) && T.pend != RT_REF_NONE)));
+                    RT_STAT(kStatStalledLanes, __popcll(ballot(tracing && T.cur != RT_REF_NONE && ref_is_leaf<FMT>(T.cur) && T.pend != RT_REF_NONE)));
                 }
 #endif
 #ifdef RT_TRAV_STATS
@@ -1445,13 +1513,13 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                 // a stack that starts the step below fast_limit ends it at most three entries higher: the pop of the
                 // leaf parking below finds its entry in LDS too
                 const bool lds_only = T.sp < K.fast_limit;
-                if (!(T.cur & kLeafBit)) node_step<FMT, DET>(T, S, K);
+                if (!ref_is_leaf<FMT>(T.cur)) node_step<FMT, DET>(T, S, K);
 #ifdef RT_TRAV_STATS
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the step's stack reads have come back
                 RT_STAT(kStatNodeClocks, __builtin_readcyclecounter() - clk_n0);
 #endif
                 // park a reached leaf in the pending slot and go on with the next stack entry
-                if (T.pend == RT_REF_NONE && T.cur != RT_REF_NONE && (T.cur & kLeafBit)) {
+                if (T.pend == RT_REF_NONE && T.cur != RT_REF_NONE && ref_is_leaf<FMT>(T.cur)) {
                     T.pend = T.cur;
                     RT_CULL_SYNC(T); // every leaf parked before this one has been tested by now
                     if (__builtin_expect(lds_only, 1)) {
@@ -1468,13 +1536,13 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
                 const bool want_leaf = T.pend != RT_REF_NONE;
                 const unsigned long long leaf_mask = ballot(want_leaf);
                 if (leaf_mask != 0ull) {
-                    const unsigned long long node_mask = ballot(!(T.cur & kLeafBit));
+                    const unsigned long long node_mask = ballot(!ref_is_leaf<FMT>(T.cur));
                     if (node_mask == 0ull || (int)__popcll(leaf_mask) >= batch_eff) {
                         RT_STAT(kStatLeafFires, 1);
                         RT_STAT(kStatLeafLanes, __popcll(leaf_mask));
 #ifdef RT_TRAV_STATS
                         {
-                            uint32_t np = want_leaf ? ((T.pend >> 28) & 7u) + 1u : 0u;
+                            uint32_t np = want_leaf ? leaf_count<FMT>(T.pend) : 0u;
                             for (int o = 32; o > 0; o >>= 1) np += __shfl_xor(np, o);
                             RT_STAT(kStatLeafPrims, np);
                         }
@@ -1482,7 +1550,7 @@ __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFra
 #ifdef RT_TRAV_STATS
                         const unsigned long long clk_l0 = __builtin_readcyclecounter();
 #endif
-                        leaf_fire(T, S, cur, want_leaf, leaf_mask, lds_addr(s_child));
+                        leaf_fire<FMT>(T, S, cur, want_leaf, leaf_mask, lds_addr(s_child));
 #ifdef RT_TRAV_STATS
                         RT_STAT(kStatLeafClocks, __builtin_readcyclecounter() - clk_l0);
 #endif
@@ -1579,8 +1647,8 @@ __global__ void __launch_bounds__(64, 6) k_trace_queue(KernelScene S, PersistArg
             const unsigned long long act = ballot(tracing);
             if (act == 0ull) break;
             if (!exhausted && (int)__popcll(act) < P.threshold) break;
-            if (tracing && !(T.cur & kLeafBit)) node_step<FMT, DET>(T, S, K);
-            if (tracing && T.pend == RT_REF_NONE && T.cur != RT_REF_NONE && (T.cur & kLeafBit)) {
+            if (tracing && !ref_is_leaf<FMT>(T.cur)) node_step<FMT, DET>(T, S, K);
+            if (tracing && T.pend == RT_REF_NONE && T.cur != RT_REF_NONE && ref_is_leaf<FMT>(T.cur)) {
                 T.pend = T.cur;
                     RT_CULL_SYNC(T); // every leaf parked before this one has been tested by now
                 T.cur = pop_or_none(K, T.sp);
@@ -1588,16 +1656,16 @@ __global__ void __launch_bounds__(64, 6) k_trace_queue(KernelScene S, PersistArg
             const bool want_leaf = tracing && T.pend != RT_REF_NONE;
             const unsigned long long leaf_mask = ballot(want_leaf);
             if (leaf_mask != 0ull) {
-                const unsigned long long node_mask = ballot(tracing && !(T.cur & kLeafBit));
+                const unsigned long long node_mask = ballot(tracing && !ref_is_leaf<FMT>(T.cur));
                 // once the rays have run out the batch is a share of the lanes still tracing
                 const int batch_eff = exhausted ? (P.leaf_batch * (int)__popcll(act) + 63) >> 6 : P.leaf_batch;
                 if (node_mask == 0ull || (int)__popcll(leaf_mask) >= batch_eff)
-                    leaf_fire(T, S, cur, want_leaf, leaf_mask, lds_addr(s_child));
+                    leaf_fire<FMT>(T, S, cur, want_leaf, leaf_mask, lds_addr(s_child));
             }
             if (tracing && T.cur == RT_REF_NONE && T.pend == RT_REF_NONE) {
                 tracing = false;
                 if (T.best_rank != RT_NO_HIT) {
-                    Q.ids[my_ray] = __float_as_int(S.prims[3 * (size_t)T.best_rank + 2].z);
+                    Q.ids[my_ray] = __float_as_int(S.prims[PrimIndex<FMT>::stride * (size_t)T.best_rank + 2].z);
                     Q.ts[my_ray] = T.best_t;
                 } else {
                     Q.ids[my_ray] = -1;
@@ -1802,14 +1870,14 @@ __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, 
             const bool tracing = t_status == RT_T_TRACING;
 #ifdef RT_TRAV_STATS
             {
-                const int nl = __popcll(ballot(tracing && !(T.cur & kLeafBit)));
+                const int nl = __popcll(ballot(tracing && !ref_is_leaf<FMT>(T.cur)));
                 RT_STAT(kStatNodeLanes, nl);
                 RT_STAT(kStatNodeIters, nl != 0);
-                RT_STAT(kStatStalledLanes, __popcll(ballot(tracing && T.cur != RT_REF_NONE && (T.cur & kLeafBit) && T.pend != RT_REF_NONE)));
+                RT_STAT(kStatStalledLanes, __popcll(ballot(tracing && T.cur != RT_REF_NONE && ref_is_leaf<FMT>(T.cur) && T.pend != RT_REF_NONE)));
             }
 #endif
-            if (tracing && !(T.cur & kLeafBit)) node_step<FMT, DET>(T, S, K);
-            if (tracing && T.pend == RT_REF_NONE && T.cur != RT_REF_NONE && (T.cur & kLeafBit)) {
+            if (tracing && !ref_is_leaf<FMT>(T.cur)) node_step<FMT, DET>(T, S, K);
+            if (tracing && T.pend == RT_REF_NONE && T.cur != RT_REF_NONE && ref_is_leaf<FMT>(T.cur)) {
                 T.pend = T.cur;
                     RT_CULL_SYNC(T); // every leaf parked before this one has been tested by now
                 T.cur = pop_or_none(K, T.sp);
@@ -1817,12 +1885,12 @@ __global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, 
             const bool want_leaf = tracing && T.pend != RT_REF_NONE;
             const unsigned long long leaf_mask = ballot(want_leaf);
             if (leaf_mask != 0ull) {
-                const unsigned long long node_mask = ballot(tracing && !(T.cur & kLeafBit));
+                const unsigned long long node_mask = ballot(tracing && !ref_is_leaf<FMT>(T.cur));
                 if (node_mask == 0ull || (int)__popcll(leaf_mask) >= P.leaf_batch) {
                     RT_STAT(kStatLeafFires, 1);
                     RT_STAT(kStatLeafLanes, __popcll(leaf_mask));
                     if (want_leaf) {
-                        leaf_test(T, S, cur, T.pend);
+                        leaf_test<FMT>(T, S, cur, T.pend);
                         T.pend = RT_REF_NONE;
                     }
                 }
@@ -1909,6 +1977,10 @@ hipError_t launch_trace_queue(const KernelScene &S, const PersistLaunch &L, cons
     const uint32_t waves = std::min<uint32_t>((uint32_t)L.grid_waves, (n + 63u) / 64u);
     if (L.node_format == 0)
         hipLaunchKernelGGL((k_trace_queue<0, true>), dim3(waves), dim3(64), lds, stream, S, P, Q);
+    else if (L.node_format == 2 && L.deterministic)
+        hipLaunchKernelGGL((k_trace_queue<2, true>), dim3(waves), dim3(64), lds, stream, S, P, Q);
+    else if (L.node_format == 2)
+        hipLaunchKernelGGL((k_trace_queue<2, false>), dim3(waves), dim3(64), lds, stream, S, P, Q);
     else if (L.deterministic)
         hipLaunchKernelGGL((k_trace_queue<1, true>), dim3(waves), dim3(64), lds, stream, S, P, Q);
     else
@@ -1973,6 +2045,26 @@ hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &
     // DET 0 (cull against the freshest hit, results timing-dependent on ~10^-10 of rays) exists only where it differs:
     // speculative traversal over quantised nodes
     const bool det = L.deterministic || !L.speculative || L.node_format == 0;
+    if (L.node_format == 2) { // packed scene: speculative traversal only
+        if (!L.speculative || L.dual) return hipErrorInvalidValue;
+        if (mode == 0 && S.uv != nullptr) {
+            if (det)
+                hipLaunchKernelGGL((k_persistent<0, 2, 1, 4, true, true>), grid, block, lds, stream, S, F, P, fb, ids, ts);
+            else
+                hipLaunchKernelGGL((k_persistent<0, 2, 1, 4, true, false>), grid, block, lds, stream, S, F, P, fb, ids, ts);
+        } else if (mode == 0) {
+            if (det)
+                hipLaunchKernelGGL((k_persistent<0, 2, 1, 6, false, true>), grid, block, lds, stream, S, F, P, fb, ids, ts);
+            else
+                hipLaunchKernelGGL((k_persistent<0, 2, 1, 6, false, false>), grid, block, lds, stream, S, F, P, fb, ids, ts);
+        } else {
+            if (det)
+                hipLaunchKernelGGL((k_persistent<1, 2, 1, 6, false, true>), grid, block, lds, stream, S, F, P, fb, ids, ts);
+            else
+                hipLaunchKernelGGL((k_persistent<1, 2, 1, 6, false, false>), grid, block, lds, stream, S, F, P, fb, ids, ts);
+        }
+        return hipGetLastError();
+    }
     if (mode == 0 && S.uv != nullptr) { // textured scene: the instances with the texture path, 128 VGPRs (4 waves/SIMD)
         if (L.node_format == 0 && !L.speculative)
             hipLaunchKernelGGL((k_persistent<0, 0, 0, 4, true, true>), grid, block, lds, stream, S, F, P, fb, ids, ts);

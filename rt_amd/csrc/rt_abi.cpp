@@ -73,6 +73,11 @@ struct rt_ctx {
     size_t n_wide = 0, n_prims = 0; // sizes of the device scene (c->wide is empty for an imported one)
 
     void *d_nodes = nullptr, *d_qnodes = nullptr, *d_prims = nullptr, *d_shade = nullptr;
+    // the packed scene (RT_OPT_NODE_FORMAT 2, rt_types.h): nodes and primitives in one record array, and the shading /
+    // texture-coordinate records indexed by the same record numbers (the entries of node records are unused)
+    void *d_pack = nullptr, *d_pshade = nullptr, *d_puv = nullptr;
+    size_t n_pack = 0;          // records in d_pack
+    std::string pack_why;       // why the scene has no packed form (then format 1 runs)
     DevMat *d_mats = nullptr;
     float *d_fb = nullptr;
     size_t fb_pixels = 0;
@@ -165,7 +170,12 @@ void free_scene(rt_ctx *c) {
     if (c->d_prims) (void)hipFree(c->d_prims);
     if (c->d_shade) (void)hipFree(c->d_shade);
     if (c->d_uv) (void)hipFree(c->d_uv);
+    if (c->d_pack) (void)hipFree(c->d_pack);
+    if (c->d_pshade) (void)hipFree(c->d_pshade);
+    if (c->d_puv) (void)hipFree(c->d_puv);
     c->d_nodes = c->d_qnodes = c->d_prims = c->d_shade = c->d_uv = nullptr;
+    c->d_pack = c->d_pshade = c->d_puv = nullptr;
+    c->n_pack = 0;
     c->scene_on_device = false;
 }
 
@@ -182,6 +192,34 @@ bool make_device_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *
     build_sah_bvh(tris, n, sah);
     // the SAH nodes carry un-padded boxes: always re-fit + pad (box mode 0)
     return build_wide_bvh(tris, n, sah.data(), (int)sah.size(), leaf_size, 0, ref_rank.data(), wide, err, collapse);
+}
+
+// The packed form of the scene that c->wide holds (format 2).  A tree that does not fit the format is not an error:
+// pack_why says why and format 1 runs.
+int upload_pack_scene(rt_ctx *c) {
+    PackScene ps;
+    c->pack_why.clear();
+    if (!build_pack_scene(c->wide, ps, c->pack_why)) return RT_OK;
+    const size_t n = ps.recs.size();
+    HIPCHK(c, hipMalloc(&c->d_pack, n * sizeof(PackRecord)));
+    HIPCHK(c, hipMemcpy(c->d_pack, ps.recs.data(), n * sizeof(PackRecord), hipMemcpyHostToDevice));
+    std::vector<PackRecord>().swap(ps.recs);
+    {
+        std::vector<DevShade> sh(n);
+        std::memset(sh.data(), 0, n * sizeof(DevShade));
+        for (size_t p = 0; p < c->wide.shade.size(); p++) sh[ps.rec_of_prim[p]] = c->wide.shade[p];
+        HIPCHK(c, hipMalloc(&c->d_pshade, n * sizeof(DevShade)));
+        HIPCHK(c, hipMemcpy(c->d_pshade, sh.data(), n * sizeof(DevShade), hipMemcpyHostToDevice));
+    }
+    if (!c->wide.uv.empty()) {
+        std::vector<DevUV> uv(n);
+        std::memset(uv.data(), 0, n * sizeof(DevUV));
+        for (size_t p = 0; p < c->wide.uv.size(); p++) uv[ps.rec_of_prim[p]] = c->wide.uv[p];
+        HIPCHK(c, hipMalloc(&c->d_puv, n * sizeof(DevUV)));
+        HIPCHK(c, hipMemcpy(c->d_puv, uv.data(), n * sizeof(DevUV), hipMemcpyHostToDevice));
+    }
+    c->n_pack = n;
+    return RT_OK;
 }
 
 int upload_scene(rt_ctx *c) {
@@ -210,6 +248,10 @@ int upload_scene(rt_ctx *c) {
         HIPCHK(c, hipMemcpyAsync(c->d_uv, c->wide.uv.data(), ub, hipMemcpyHostToDevice, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->node_format == 2) {
+        int rc = upload_pack_scene(c);
+        if (rc) return rc;
+    }
     c->scene_on_device = true;
     c->imported = false;
     c->n_wide = c->wide.qnodes.size();
@@ -480,15 +522,29 @@ void fill_frame(rt_ctx *c, KernelFrame &F) {
     F.raw_sum = c->raw_sum;
 }
 
+// The node format a launch runs with: the packed scene needs its device arrays (a tree that does not fit the format has
+// none: pack_why) and exists for the speculative persistent kernels only; otherwise format 2 means format 1.
+int effective_format(const rt_ctx *c) {
+    if (c->node_format != 2) return c->node_format;
+    return c->d_pack && c->kernel_variant == 2 ? 2 : 1;
+}
+
 KernelScene scene_of(rt_ctx *c) {
     KernelScene S;
     S.nodes = (const float4 *)c->d_nodes;
+    S.mats = c->d_mats;
+    S.tex = c->d_tex;
+    if (effective_format(c) == 2) { // one record array is both the node and the primitive array
+        S.qnodes = (const uint4 *)c->d_pack;
+        S.prims = (const float4 *)c->d_pack;
+        S.shade = (const float4 *)c->d_pshade;
+        S.uv = (const float4 *)c->d_puv;
+        return S;
+    }
     S.qnodes = (const uint4 *)c->d_qnodes;
     S.prims = (const float4 *)c->d_prims;
     S.shade = (const float4 *)c->d_shade;
-    S.mats = c->d_mats;
     S.uv = (const float4 *)c->d_uv;
-    S.tex = c->d_tex;
     return S;
 }
 
@@ -545,7 +601,7 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_ra
     L.grid_waves = c->n_cus * per_cu;
     L.lds_entries = c->lds_stack < c->wide.stack_entries ? c->lds_stack : c->wide.stack_entries;
     L.threshold = c->refill_threshold;
-    L.node_format = c->node_format;
+    L.node_format = effective_format(c);
     L.speculative = c->kernel_variant >= 2 ? 1 : 0;
     L.deterministic = c->deterministic;
     L.dual = c->kernel_variant == 3 ? 1 : 0;
@@ -928,7 +984,10 @@ int rt_set_option(rt_ctx *c, int option, int64_t value) {
         c->lds_stack = (int)value;
         return RT_OK;
     case RT_OPT_NODE_FORMAT:
-        if (value != 0 && value != 1) return fail(c, RT_E_ARG, "node format 0 or 1");
+        if (value < 0 || value > 2) return fail(c, RT_E_ARG, "node format 0, 1 or 2");
+        // the packed scene is laid out and uploaded on demand; an imported scene has no host layout to pack and keeps
+        // running format 1 (effective_format)
+        if (value == 2 && !c->d_pack && !c->imported) c->scene_on_device = false;
         c->node_format = (int)value;
         return RT_OK;
     case RT_OPT_LEAF_BATCH:
@@ -1276,6 +1335,26 @@ int rt_test_wide_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *
     if (wide_nodes) std::memcpy(wide_nodes, w.nodes.data(), w.nodes.size() * sizeof(WideNode));
     if (quant_nodes) std::memcpy(quant_nodes, w.qnodes.data(), w.qnodes.size() * sizeof(QuantNode));
     if (prims) std::memcpy(prims, w.prims.data(), w.prims.size() * sizeof(DevPrim));
+    return RT_OK;
+    RT_CATCH(nullptr)
+}
+
+int rt_test_pack_layout(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size, int topology,
+                        void *records, uint32_t *rec_of_prim, int64_t info[2]) {
+    RT_TRY
+    if (!tris || !nodes || !info) return RT_E_ARG;
+    WideBvh w;
+    std::string err;
+    if (topology < 0 || topology > 3) return RT_E_ARG;
+    if (!make_device_layout(tris, n, nodes, m, leaf_size, 0, topology & 1, w, err, topology >> 1)) return RT_E_ARG;
+    PackScene ps;
+    std::string why;
+    info[0] = info[1] = 0;
+    if (!build_pack_scene(w, ps, why)) return RT_OK; // does not fit the format: zero records
+    info[0] = (int64_t)ps.recs.size();
+    info[1] = (int64_t)w.qnodes.size();
+    if (records) std::memcpy(records, ps.recs.data(), ps.recs.size() * sizeof(PackRecord));
+    if (rec_of_prim) std::memcpy(rec_of_prim, ps.rec_of_prim.data(), ps.rec_of_prim.size() * sizeof(uint32_t));
     return RT_OK;
     RT_CATCH(nullptr)
 }

@@ -34,7 +34,34 @@ struct QuantNode {
 };
 static_assert(sizeof(QuantNode) == 64, "QuantNode must be 64 bytes");
 
-// child reference encoding
+// ---- packed scene (RT_OPT_NODE_FORMAT 2): ONE array of 48-byte records, wide nodes and primitives together ----
+// A node visit is THREE 16-byte loads instead of four.  What makes the room: the grid steps are exponent bytes, and the
+// four child references are not stored but rebuilt from one base and a byte per child.  That needs one address space
+// for both kinds of children, so nodes (PackNode) and primitives (DevPrim, unchanged) live in the same array, addressed
+// in UNITS of 16 bytes (record r starts at unit 3 r; the root is record 0): the children of a node -- one record per
+// inner child, one per primitive of a leaf child, in slot order -- follow each other in one block, so a node's children
+// are also its neighbours in memory.
+//   16 B: origin x, y, z (float), child bytes (child c in byte c)
+//   16 B: qlo_x[4], qhi_x[4], qlo_y[4], qhi_y[4]      (as QuantNode: the same boxes, bit for bit)
+//   16 B: qlo_z[4], qhi_z[4], base4 = 4 * (first unit of the child block), grid exponents x | y << 8 | z << 16 (int8 each)
+// child byte = (units from the block's start) << 2 | leaf << 1 | (primitives in the leaf - 1); kPackEmpty = unused slot
+// reference  = base4 + child byte = unit << 2 | leaf << 1 | (count - 1): two instructions (v_bfe_u32, v_add_u32) per child.
+// Limits, checked by the host (build_pack_scene), which otherwise leaves the packed scene empty and format 1 runs:
+// leaves of at most two primitives (RT_OPT_LEAF_SIZE <= 2); fewer than 2^28 units = 4 GiB (32-bit byte offsets).
+struct PackNode {
+    float origin[3];
+    uint32_t child_bytes;
+    uint32_t qx_lo, qx_hi, qy_lo, qy_hi;
+    uint32_t qz_lo, qz_hi;
+    uint32_t base4;
+    uint32_t exps;
+};
+static_assert(sizeof(PackNode) == 48, "PackNode must be 48 bytes");
+constexpr uint32_t kPackLeafBit = 2u;    // in a packed reference
+constexpr uint32_t kPackEmpty = 0xFFu;   // child byte of an unused slot (offset 63 is beyond any block: at most 8 records)
+constexpr uint64_t kPackMaxUnits = (uint64_t)1 << 28;
+
+// child reference encoding (formats 0 and 1)
 constexpr uint32_t kLeafBit = 0x80000000u;  // leaf: bits 0..27 first primitive (DFS rank), bits 28..30 count-1
 constexpr uint32_t kEmptyRef = 0xFFFFFFFFu; // unused slot (its box is inverted and can never be hit)
 constexpr uint32_t kLeafStartMask = 0x0FFFFFFFu;

@@ -414,4 +414,65 @@ bool build_wide_bvh(const rt_triangle148 *tris, int n, const rt_bvh_node32 *node
     return true;
 }
 
+bool build_pack_scene(const WideBvh &w, PackScene &out, std::string &why) {
+    out.recs.clear();
+    out.rec_of_prim.clear();
+    const size_t n_wide = w.qnodes.size(), n_prims = w.prims.size();
+    if (n_wide == 0 || n_prims == 0) return why = "no scene", false;
+    if (3 * (uint64_t)(n_wide + n_prims) >= kPackMaxUnits) return why = "2^28 units or more", false;
+    out.recs.resize(n_wide + n_prims);
+    out.rec_of_prim.assign(n_prims, 0xFFFFFFFFu);
+    // wide nodes are in breadth-first order and every child has a larger index than its parent: walking them by index,
+    // a node's own record is known (its parent placed it) by the time its child block is laid down
+    std::vector<uint32_t> rec_of_node(n_wide, 0xFFFFFFFFu);
+    rec_of_node[0] = 0;
+    uint32_t next = 1; // next free record
+    for (size_t i = 0; i < n_wide; i++) {
+        const QuantNode &q = w.qnodes[i];
+        if (rec_of_node[i] == 0xFFFFFFFFu) return out.recs.clear(), out.rec_of_prim.clear(), why = "internal: unreferenced wide node", false;
+        PackNode pk;
+        std::memcpy(pk.origin, q.origin, sizeof(pk.origin));
+        pk.qx_lo = q.qx_lo, pk.qx_hi = q.qx_hi, pk.qy_lo = q.qy_lo, pk.qy_hi = q.qy_hi, pk.qz_lo = q.qz_lo, pk.qz_hi = q.qz_hi;
+        const float steps[3] = {q.step_x, q.step_y, q.step_z};
+        uint32_t exps = 0;
+        for (int a = 0; a < 3; a++) {
+            int e = 0;
+            const float m = std::frexp(steps[a], &e); // step = m * 2^e, m = 0.5 for a power of two
+            e -= 1;
+            if (m != 0.5f || e < -126 || e > 126) return out.recs.clear(), out.rec_of_prim.clear(), why = "grid step is not a normal power of two", false;
+            exps |= ((uint32_t)e & 0xFFu) << (8 * a);
+        }
+        pk.exps = exps;
+        const uint32_t block = next;
+        pk.base4 = 4u * 3u * block;
+        uint32_t bytes = 0;
+        for (int s = 0; s < 4; s++) {
+            const uint32_t r = q.child[s];
+            uint32_t b = kPackEmpty;
+            if (r != kEmptyRef && (r & kLeafBit)) {
+                const uint32_t first = r & kLeafStartMask, cnt = ((r >> 28) & 7u) + 1u;
+                if (cnt > 2u) return out.recs.clear(), out.rec_of_prim.clear(), why = "a leaf holds more than two primitives", false;
+                b = (3u * (next - block)) << 2 | kPackLeafBit | (cnt - 1u);
+                for (uint32_t k = 0; k < cnt; k++) {
+                    if (first + k >= n_prims || out.rec_of_prim[first + k] != 0xFFFFFFFFu)
+                        return out.recs.clear(), out.rec_of_prim.clear(), why = "internal: leaves do not partition the primitives", false;
+                    out.rec_of_prim[first + k] = next;
+                    std::memcpy(&out.recs[next], &w.prims[first + k], sizeof(PackRecord));
+                    next++;
+                }
+            } else if (r != kEmptyRef) {
+                if (r >= n_wide || r <= i || rec_of_node[r] != 0xFFFFFFFFu)
+                    return out.recs.clear(), out.rec_of_prim.clear(), why = "internal: child reference out of order", false;
+                b = (3u * (next - block)) << 2;
+                rec_of_node[r] = next++;
+            }
+            bytes |= b << (8 * s);
+        }
+        pk.child_bytes = bytes;
+        std::memcpy(&out.recs[rec_of_node[i]], &pk, sizeof(PackRecord));
+    }
+    if (next != n_wide + n_prims) return out.recs.clear(), out.rec_of_prim.clear(), why = "internal: records do not add up", false;
+    return true;
+}
+
 } // namespace rtamd

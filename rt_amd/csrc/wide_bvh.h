@@ -32,6 +32,21 @@ struct WideBvh {
 bool build_wide_bvh(const rt_triangle148 *tris, int n, const rt_bvh_node32 *nodes, int m, int leaf_size, int box_mode,
                     const int32_t *ref_rank, WideBvh &out, std::string &err, int collapse = 0);
 
+// The packed scene of RT_OPT_NODE_FORMAT 2 (rt_types.h, PackNode): wide nodes and primitives in ONE array of 48-byte
+// records, every node's children in one block.  Built from a finished WideBvh: the same boxes (the quantised values of
+// qnodes, bit for bit), the same primitives, the same tie-break ranks, so traced results cannot differ.
+struct PackRecord {
+    uint32_t w[12];
+};
+static_assert(sizeof(PackRecord) == 48 && sizeof(PackRecord) == sizeof(PackNode) && sizeof(PackRecord) == sizeof(DevPrim), "one record size");
+struct PackScene {
+    std::vector<PackRecord> recs;      // record 0 = the root node; qnodes.size() + prims.size() records
+    std::vector<uint32_t> rec_of_prim; // rec_of_prim[p] = record that holds WideBvh::prims[p]
+};
+// false, with the reason in `why` and `out` empty, when the tree does not fit the format (a leaf of more than two
+// primitives, 2^28 units or more, a grid exponent beyond int8): the caller then runs format 1.
+bool build_pack_scene(const WideBvh &w, PackScene &out, std::string &why);
+
 // DFS (left first) leaf order of a binary tree: order[rank] = primitive.  Validates that `nodes` is a tree over
 // exactly the n primitives.
 bool dfs_leaf_order(const rt_bvh_node32 *nodes, int m, int n, std::vector<int32_t> &order, std::string &err);

@@ -74,7 +74,7 @@ ABI_SYMBOLS = [
     "rt_write_ppm", "rt_test_glibc_rand", "rt_test_introsort", "rt_test_build_bvh", "rt_test_wide_layout", "rt_test_tile_owner", "rt_test_fastdiv",
     "rt_test_trav_stats", "rt_test_sincosf", "rt_set_texture", "rt_trace_rays_device", "rt_test_dump_rays", "rt_test_wave_times",
     "rt_test_trace_dumped", "rt_render_device_noalloc", "rt_test_sort_dumped", "rt_export_scene", "rt_import_scene",
-    "rt_test_scene_blob", "rt_test_scene_blob_info", "rt_test_scene_blob_check",
+    "rt_test_scene_blob", "rt_test_scene_blob_info", "rt_test_scene_blob_check", "rt_test_pack_layout",
 ]
 
 
@@ -125,6 +125,7 @@ def load_library(path: str = LIB_PATH):
     lib.rt_test_tile_owner.argtypes = [C.c_int, C.c_int, C.c_int, vp]
     lib.rt_test_fastdiv.argtypes = [C.c_uint32, vp, C.c_int, vp]
     lib.rt_test_wide_layout.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.rt_test_pack_layout.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     for name in ABI_SYMBOLS:
         if name != "rt_last_error":
             getattr(lib, name).restype = C.c_int
@@ -193,6 +194,28 @@ def host_wide_layout(tris: np.ndarray, nodes: np.ndarray, leaf_size: int = 1, bo
     if quant:
         return wide, qn, prims, int(info[2]), int(info[3])
     return wide, prims, int(info[2]), int(info[3])
+
+
+PACK_NODE_DTYPE = np.dtype([("origin", "<f4", 3), ("child_bytes", "<u4"), ("q", "<u4", 6), ("base4", "<u4"), ("exps", "<u4")])
+
+
+def host_pack_layout(tris: np.ndarray, nodes: np.ndarray, leaf_size: int = 2, topology: int = 3):
+    """The packed scene of RT_OPT_NODE_FORMAT 2 alone (no GPU): (records as uint32[n, 12], rec_of_prim, wide nodes among
+    the records), or None when the tree does not fit the format."""
+    lib = load_library()
+    tris = np.ascontiguousarray(tris, dtype=TRI_DTYPE)
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    info = np.zeros(2, dtype=np.int64)
+    args = (_ptr(tris), tris.shape[0], _ptr(nodes), nodes.shape[0], leaf_size, topology)
+    if lib.rt_test_pack_layout(*args, None, None, _ptr(info)):
+        raise RtError("rt_test_pack_layout failed")
+    if info[0] == 0:
+        return None
+    recs = np.zeros((int(info[0]), 12), dtype=np.uint32)
+    rec_of_prim = np.zeros(tris.shape[0], dtype=np.uint32)
+    if lib.rt_test_pack_layout(*args, _ptr(recs), _ptr(rec_of_prim), _ptr(info)):
+        raise RtError("rt_test_pack_layout failed")
+    return recs, rec_of_prim, int(info[1])
 
 
 def host_scene_blob(tris: np.ndarray, nodes: np.ndarray, leaf_size: int = 2, box_mode: int = 0, topology: int = 3, flags: int = 0) -> np.ndarray:

@@ -204,7 +204,8 @@ def test_device_layout_options_do_not_change_results(leaf, box_mode, topo):
 @pytest.mark.parametrize("kernel,fmt,thr,batch,lds,topo", [(0, 0, 40, 24, 16, 0), (1, 0, 40, 24, 16, 0), (1, 1, 64, 24, 2, 0),
                                                           (2, 0, 16, 1, 16, 0), (2, 1, 48, 64, 4, 0), (2, 1, 1, 8, 64, 1),
                                                           (0, 0, 40, 24, 16, 1), (1, 1, 48, 8, 3, 1), (1, 0, 32, 8, 16, 1),
-                                                          (2, 1, 24, 16, 1, 1), (2, 1, 24, 16, 248, 1)])  # 1 entry: every deeper one spills; 248: the most LDS takes
+                                                          (2, 1, 24, 16, 1, 1), (2, 1, 24, 16, 248, 1),  # 1 entry: every deeper one spills; 248: the most LDS takes
+                                                          (2, 2, 24, 16, 16, 1), (2, 2, 48, 64, 1, 0), (2, 2, 1, 8, 4, 1), (2, 2, 25, 16, 248, 1)])  # format 2: the packed scene
 def test_kernel_variants_bit_exact(oracle, kernel, fmt, thr, batch, lds, topo):
     """Every kernel variant (one wave per tile / persistent refill / speculative), node format (float /
     quantized), refill threshold, leaf batch and LDS-stack size (small ones force the HBM spill path) returns the

@@ -279,6 +279,57 @@ def test_quantized_nodes_are_conservative():
                 assert (lo[~v] > hi[~v]).all()  # empty slots are inverted
 
 
+@pytest.mark.parametrize("leaf,topology", [(2, 3), (1, 3), (2, 0), (2, 1), (1, 2)])
+def test_packed_scene_is_the_quantized_tree(leaf, topology):
+    """RT_OPT_NODE_FORMAT 2: nodes and primitives in one array of 48-byte records.  Walking it from record 0 by the
+    rebuilt references (base4 + child byte) visits every record exactly once and meets, child for child, the
+    quantised tree it was made from: the same boxes (origin, byte offsets, grid step as an exponent byte), inner
+    children where the tree has inner children, and under every leaf the same primitive records in the same order.
+    A tree with larger leaves does not fit the format and is refused (format 1 then runs)."""
+    for tris in (scenes.heightfield(23), scenes.spheres_scene()):
+        nodes = engine.host_build_bvh(tris)
+        wide, qn, prims, _, _ = engine.host_wide_layout(tris, nodes, leaf, 0, quant=True, topology=topology)
+        recs, rec_of_prim, n_wide = engine.host_pack_layout(tris, nodes, leaf, topology)
+        assert n_wide == qn.shape[0] and recs.shape == (qn.shape[0] + prims.shape[0], 12)
+        assert 3 * recs.shape[0] < 2 ** 28
+        prim_words = prims.view(np.uint32).reshape(-1, 12)
+        assert (recs[rec_of_prim] == prim_words).all() and np.unique(rec_of_prim).size == prims.shape[0]
+        seen = np.zeros(recs.shape[0], dtype=np.int32)
+        todo = [(0, 0)]  # (unit address, wide node index)
+        while todo:
+            unit, i = todo.pop()
+            assert unit % 3 == 0
+            seen[unit // 3] += 1
+            pk = recs[unit // 3].view(engine.PACK_NODE_DTYPE)[0]
+            q = qn[i]
+            assert pk["origin"].tobytes() == q["origin"].tobytes() and pk["q"].tobytes() == q["q"].tobytes()
+            steps = [q["step_x"], q["step_yz"][0], q["step_yz"][1]]
+            for a in range(3):
+                e = (int(pk["exps"]) >> (8 * a)) & 0xFF
+                e = e - 256 if e >= 128 else e
+                assert np.float32(2.0) ** e == steps[a]
+            assert int(pk["base4"]) % 12 == 0 and int(pk["base4"]) // 4 > unit  # a child block lies behind its parent
+            for s in range(4):
+                ch, b = int(q["child"][s]), (int(pk["child_bytes"]) >> (8 * s)) & 0xFF
+                if ch == 0xFFFFFFFF:
+                    assert b == 0xFF
+                    continue
+                ref = int(pk["base4"]) + b
+                if ch & 0x80000000:
+                    first, cnt = ch & 0x0FFFFFFF, ((ch >> 28) & 7) + 1
+                    assert ref & 2 and (ref & 1) + 1 == cnt
+                    for k in range(cnt):
+                        r = (ref >> 2) // 3 + k
+                        assert (ref >> 2) % 3 == 0 and rec_of_prim[first + k] == r
+                        seen[r] += 1
+                else:
+                    assert ref & 3 == 0
+                    todo.append((ref >> 2, ch))
+        assert (seen == 1).all()
+    tris = scenes.heightfield(23)
+    assert engine.host_pack_layout(tris, engine.host_build_bvh(tris), 4, 3) is None  # leaves of up to four primitives
+
+
 def test_wide_layout_rejects_malformed_tree():
     tris = scenes.heightfield(4)
     nodes = engine.host_build_bvh(tris)
