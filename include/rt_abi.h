@@ -148,8 +148,8 @@ enum {
     RT_OPT_SHARD_RANK = 5,  /* multi-GPU tile sharding: this context renders the 8x8 tiles with */
     RT_OPT_SHARD_WORLD = 6, /*   tile_index % world == rank; other pixels are written as 0 */
     RT_OPT_KERNEL = 7,      /* kernel variant, see DESIGN.md: 0 = one wave per tile, 1 = persistent waves
-                               with per-lane refill, 2 = 1 + speculative traversal (postponed leaves),
-                               3 = 2 + two paths per lane (render only; primary / ray queries run as 2) */
+                               with per-lane refill, 2 = 1 + speculative traversal (postponed leaves; default).
+                               (3, two paths per lane, was a measured negative and is refused: branch exp/k-dual) */
     RT_OPT_REFILL_THRESHOLD = 8, /* kernel 1: refill when fewer than this many of 64 lanes still traverse */
     RT_OPT_WAVES_PER_CU = 9,     /* kernel 1: persistent waves launched per CU */
     RT_OPT_LDS_STACK = 10,       /* kernel 1: stack entries per lane kept in LDS (the rest spill to HBM) */
@@ -162,8 +162,8 @@ enum {
     RT_OPT_TOPOLOGY = 14,        /* device hierarchy: 0 = the reference's tree, wide-ified; 1 = a binned-SAH tree
                                     re-built over the same primitives (default).  Results are identical;
                                     rt_get_bvh_nodes always returns the reference's tree. */
-    RT_OPT_SHADE_BATCH = 15,     /* kernel 3: lanes with shading work queued that end a traversal phase */
-    RT_OPT_SWAP_BATCH = 16,      /* kernel 3: lanes waiting to exchange their two paths that trigger the exchange */
+    RT_OPT_SHADE_BATCH = 15,     /* accepted and ignored: they tuned kernel variant 3, which left the library */
+    RT_OPT_SWAP_BATCH = 16,
     RT_OPT_TAIL_SPLIT = 17,      /* kernel 1/2 render: the frame is walked in this many rounds (1..63, at most ns; default 0 = 2..8 by pixels per lane),
                                     each running ns/rounds samples of every pixel and handing the pixel's state on to
                                     whichever lane takes it next round, so that the frame ends on fractions of a pixel

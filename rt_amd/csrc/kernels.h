@@ -67,16 +67,13 @@ struct PersistLaunch {
     int lds_entries;
     int threshold;
     int grid_waves;
-    int node_format; // 0 = WideNode (128 B float), 1 = QuantNode (64 B)
+    int node_format; // 0 = WideNode (128 B float), 1 = QuantNode (64 B), 2 = packed scene (48-byte records; speculative only)
     int speculative; // 1 = postpone leaves (speculative traversal)
     int deterministic = 1; // speculative traversal over quantised nodes: 1 = cull against a value that is refreshed at points of the
                            // lane's own sequence only (reproducible results), 0 = against the freshest (RT_OPT_DETERMINISTIC)
     int leaf_batch;
     int primary_chunk = 256; // primary rays: slots per band-counter atomic (a multiple of 64)
     int occupancy; // 4, 6 or 8 waves per SIMD the kernel's registers are held to (quantized nodes only)
-    int dual;        // render only: 1 = k_dual (two paths per lane); implies speculative traversal
-    int shade_batch; // k_dual: lanes with shading work queued that end a traversal phase
-    int swap_batch;  // k_dual: lanes waiting to exchange their two paths that trigger the exchange
     // rounds (render only): the frame is walked `rounds` times, pixels hand their state on between rounds; see
     // "Rounds" at k_persistent
     int rounds;            // 1 = off; at most 63 and at most ns

@@ -1677,234 +1677,9 @@ __global__ void __launch_bounds__(64, 6) k_trace_queue(KernelScene S, PersistArg
     add_rays(Q.ray_counter, nr);
 }
 
-// ------------------------------------------------------------------ two paths per lane
-// k_persistent's counters (tools/trav_stats.py) show where its lanes go on diffuse paths: rays are short (16 node
-// steps), so a lane finishes often; with one path per lane it then sits idle until enough lanes have finished
-// to make the (expensive) shading step worth running -- 24 of 64 lanes idle in the average traversal iteration,
-// and shading itself runs with 23.  k_dual gives every lane a second path, parked in registers:
-//   slot T: the path being traversed (its ray, the traversal state, the LDS stack);
-//   slot W: a path that waits -- READY (has a ray to trace), DONE (traversal result waiting to be shaded) or EMPTY.
-// When T finishes and W is READY the two exchange (v_swap_b32: 21 instructions) and the lane keeps traversing;
-// shading always works on slot W, and runs when `shade_batch` lanes have work for it.  Paths are independent
-// (one pixel, one RNG stream each), so the order in which a lane interleaves its two paths cannot change a result.
-#define RT_W_EMPTY 0
-#define RT_W_READY 1
-#define RT_W_DONE 2
-#define RT_T_EMPTY 0
-#define RT_T_TRACING 1
-#define RT_T_DONE 2
-
-struct PathRegs { // what shading needs besides the ray and the hit: 15 registers
-    Rng g;
-    V3 col, thr;
-    uint32_t pij; // pixel: j << 16 | i
-    int k, bounce;
-};
-
-__device__ __forceinline__ void vswap(float &a, float &b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void vswap(uint32_t &a, uint32_t &b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void vswap(int &a, int &b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void vswap(V3 &a, V3 &b) {
-    vswap(a.x, b.x);
-    vswap(a.y, b.y);
-    vswap(a.z, b.z);
-}
-__device__ __forceinline__ void vswap(PathRegs &a, PathRegs &b) {
-    vswap(a.g.v0, b.g.v0);
-    vswap(a.g.v1, b.g.v1);
-    vswap(a.g.v2, b.g.v2);
-    vswap(a.g.v3, b.g.v3);
-    vswap(a.g.v4, b.g.v4);
-    vswap(a.g.d, b.g.d);
-    vswap(a.col, b.col);
-    vswap(a.thr, b.thr);
-    vswap(a.pij, b.pij);
-    vswap(a.k, b.k);
-    vswap(a.bounce, b.bounce);
-}
-
-struct DualArgs {
-    int shade_batch; // leave the traversal phase when this many lanes have shading / fetch work in slot W
-    int swap_batch;  // exchange T and W when this many lanes wait for it (or nothing else is traversing)
-};
-
-template <int FMT, int OCC>
-__global__ void __launch_bounds__(64, OCC) k_dual(KernelScene S, KernelFrame F, PersistArgs P, DualArgs D, float *fb) {
-    constexpr bool DET = true;
-    const uint32_t lane = threadIdx.x;
-    StackRef K;
-    stack_ref_init(K, lane, P.spill, P.lds_entries, P.total_lanes);
-    const uint32_t home = xcc_id();
-    const uint32_t n_tiles = (uint32_t)F.n_local_tiles;
-    SlotQueue q;
-    q.next = q.end = q.empty = q.round = q.base_slot = 0u;
-    q.band_slots = 1u;
-    q.cursor = (home + (blockIdx.x >> 3)) & 7u;
-
-    PathRegs pt, pw;
-    pt.g.v0 = pt.g.v1 = pt.g.v2 = pt.g.v3 = pt.g.v4 = pt.g.d = 0;
-    pt.col = pt.thr = mk(0, 0, 0);
-    pt.pij = 0;
-    pt.k = pt.bounce = 0;
-    pw = pt;
-    Ray cur, wr;
-    cur.o = wr.o = mk(0, 0, 0);
-    cur.d = wr.d = mk(0, 0, 1);
-    float wt = 0.0f;
-    int wrank = RT_NO_HIT;
-    int t_status = RT_T_EMPTY, w_status = RT_W_EMPTY;
-    bool retired = false;
-    Trav T;
-    trav_begin(T, cur, K.sp0);
-    T.cur = RT_REF_NONE;
-    uint32_t nr = 0;
-#ifdef RT_TRAV_STATS
-    unsigned long long st[kTravStats] = {0};
-#endif
-
-    for (;;) {
-        // ---------------- shading phase: slot W
-        RT_STAT(kStatRefills, 1);
-        RT_STAT(kStatShadeLanes, __popcll(ballot(w_status == RT_W_DONE)));
-        bool need_primary = false;
-        if (w_status == RT_W_DONE) {
-            Hit h;
-            h.t = wt;
-            h.rank = wrank;
-            bool clamp;
-            const bool go_on = shade_bounce<true>(S, h, wr, pw.thr, pw.g, clamp);
-            pw.bounce++;
-            w_status = RT_W_READY;
-            if (!go_on || pw.bounce >= F.max_depth) {
-                if (clamp) clip_color(pw.thr);
-                pw.col = vadd(pw.col, pw.thr);
-                pw.k++;
-                if (pw.k == F.ns) {
-                    V3 c = pw.col;
-                    if (!F.raw_sum) {
-                        const float kk = (float)(1.0 / (double)(float)F.ns);
-                        c = mk(pw.col.x * kk, pw.col.y * kk, pw.col.z * kk);
-                        clip_color(c);
-                    }
-                    const size_t pixel_index = (size_t)(pw.pij >> 16) * (size_t)F.nx + (size_t)(pw.pij & 0xFFFFu);
-                    fb[3 * pixel_index + 0] = c.x;
-                    fb[3 * pixel_index + 1] = c.y;
-                    fb[3 * pixel_index + 2] = c.z;
-                    w_status = RT_W_EMPTY;
-                } else {
-                    need_primary = true;
-                }
-            }
-        }
-        {
-            uint32_t slot = 0;
-            const bool need = w_status == RT_W_EMPTY && !retired;
-            RT_STAT(kStatFetchLanes, __popcll(ballot(need)));
-            uint32_t round = 0;
-            const bool got = fetch_slot(64u, P.band_counters, n_tiles, home, q, need, slot, 1u, round);
-            if (need) {
-                if (!got) {
-                    retired = true;
-                } else {
-                    const uint32_t local = slot >> 6, within = slot & 63u;
-                    const uint32_t gt = local * (uint32_t)F.shard_world + (uint32_t)F.shard_rank;
-                    int tx, ty;
-                    tile_xy(F, gt, tx, ty);
-                    const int pi = tx * 8 + (int)(within & 7u), pj = ty * 8 + (int)(within >> 3);
-                    if (pi < F.nx && pj < F.ny) { // ragged edge tiles: the slot is simply dropped
-                        pw.pij = ((uint32_t)pj << 16) | (uint32_t)pi;
-                        rng_init(pw.g, (uint64_t)(1995 + pj * F.nx + pi) + F.seed_salt);
-                        pw.col = mk(0, 0, 0);
-                        pw.k = 0;
-                        need_primary = true;
-                    }
-                }
-            }
-        }
-        RT_STAT(kStatPrimaryLanes, __popcll(ballot(need_primary)));
-        if (need_primary) {
-            wr = primary_ray(F.cam, (int)(pw.pij & 0xFFFFu), (int)(pw.pij >> 16), F.nx, F.ny, pw.g);
-            pw.thr = mk(1.0f, 1.0f, 1.0f);
-            pw.bounce = 0;
-            w_status = RT_W_READY;
-        }
-        if (ballot(!(retired && t_status == RT_T_EMPTY && w_status == RT_W_EMPTY)) == 0ull) break;
-
-        // ---------------- traversal phase: slot T
-        for (;;) {
-            unsigned long long act = ballot(t_status == RT_T_TRACING);
-            {
-                // T has nothing to traverse and W has a ray, or T holds a result and W is free to take it
-                const bool want = t_status != RT_T_TRACING &&
-                                  (w_status == RT_W_READY || (t_status == RT_T_DONE && w_status == RT_W_EMPTY));
-                const unsigned long long sw = ballot(want);
-                if (sw != 0ull && ((int)__popcll(sw) >= D.swap_batch || act == 0ull)) {
-                    if (want) {
-                        vswap(pt, pw);
-                        vswap(cur.o, wr.o);
-                        vswap(cur.d, wr.d);
-                        wt = T.best_t;
-                        wrank = T.best_rank;
-                        const int new_w = t_status == RT_T_DONE ? RT_W_DONE : RT_W_EMPTY;
-                        if (w_status == RT_W_READY) {
-                            trav_begin(T, cur, K.sp0);
-                            t_status = RT_T_TRACING;
-                            nr++;
-                        } else {
-                            t_status = RT_T_EMPTY;
-                        }
-                        w_status = new_w;
-                    }
-                    act = ballot(t_status == RT_T_TRACING);
-                }
-            }
-            if (act == 0ull) break;
-            {
-                const unsigned long long work = ballot(w_status == RT_W_DONE || (w_status == RT_W_EMPTY && !retired));
-                if ((int)__popcll(work) >= D.shade_batch) break;
-                if ((int)__popcll(act) < P.threshold && work != 0ull) break;
-            }
-            RT_STAT(kStatIters, 1);
-            RT_STAT(kStatIdleLanes, 64 - __popcll(act));
-            RT_STAT(kStatRetiredLanes, __popcll(ballot(retired && t_status == RT_T_EMPTY && w_status == RT_W_EMPTY)));
-            const bool tracing = t_status == RT_T_TRACING;
-#ifdef RT_TRAV_STATS
-            {
-                const int nl = __popcll(ballot(tracing && !ref_is_leaf<FMT>(T.cur)));
-                RT_STAT(kStatNodeLanes, nl);
-                RT_STAT(kStatNodeIters, nl != 0);
-                RT_STAT(kStatStalledLanes, __popcll(ballot(tracing && T.cur != RT_REF_NONE && ref_is_leaf<FMT>(T.cur) && T.pend != RT_REF_NONE)));
-            }
-#endif
-            if (tracing && !ref_is_leaf<FMT>(T.cur)) node_step<FMT, DET>(T, S, K);
-            if (tracing && T.pend == RT_REF_NONE && T.cur != RT_REF_NONE && ref_is_leaf<FMT>(T.cur)) {
-                T.pend = T.cur;
-                    RT_CULL_SYNC(T); // every leaf parked before this one has been tested by now
-                T.cur = pop_or_none(K, T.sp);
-            }
-            const bool want_leaf = tracing && T.pend != RT_REF_NONE;
-            const unsigned long long leaf_mask = ballot(want_leaf);
-            if (leaf_mask != 0ull) {
-                const unsigned long long node_mask = ballot(tracing && !ref_is_leaf<FMT>(T.cur));
-                if (node_mask == 0ull || (int)__popcll(leaf_mask) >= P.leaf_batch) {
-                    RT_STAT(kStatLeafFires, 1);
-                    RT_STAT(kStatLeafLanes, __popcll(leaf_mask));
-                    if (want_leaf) {
-                        leaf_test<FMT>(T, S, cur, T.pend);
-                        T.pend = RT_REF_NONE;
-                    }
-                }
-            }
-            if (tracing && T.cur == RT_REF_NONE && T.pend == RT_REF_NONE) t_status = RT_T_DONE;
-        }
-    }
-    add_rays(F.ray_counter, nr);
-#ifdef RT_TRAV_STATS
-    if (lane == 0 && P.stats)
-        for (int i = 0; i < kTravStats; i++)
-            if (st[i]) atomicAdd(&P.stats[i], st[i]);
-#endif
-}
+// (A kernel with two paths per lane -- the traced one exchanged with a parked one by v_swap_b32 when it finishes,
+// shading batched on the parked one -- was built and measured in round 1: bit-exact, 116 VGPRs, 4 waves per SIMD, 73 ms
+// against 62 ms.  It lives on branch exp/k-dual.)
 
 // ------------------------------------------------------------------ static scratch (kernels.h, static_scratch)
 // In host code the array's name is only a stand-in for the symbol: it is never passed to a kernel or to a HIP call as
@@ -2029,24 +1804,11 @@ hipError_t launch_persistent(int mode, const KernelScene &S, const KernelFrame &
                          (uint64_t)F.n_local_tiles * 64u >= (1ull << 26) || ring_bytes > 0xFFFFFFFFull))
         return hipErrorInvalidValue;
     const dim3 grid(L.grid_waves), block(64);
-    if (mode == 0 && L.dual) {
-        DualArgs D;
-        D.shade_batch = L.shade_batch;
-        D.swap_batch = L.swap_batch;
-        if (F.nx > 65535 || F.ny > 65535) return hipErrorInvalidValue; // pixel coordinates are packed 16:16
-        if (L.node_format == 0)
-            hipLaunchKernelGGL((k_dual<0, 4>), grid, block, lds, stream, S, F, P, D, fb);
-        else if (L.occupancy >= 6)
-            hipLaunchKernelGGL((k_dual<1, 6>), grid, block, lds, stream, S, F, P, D, fb);
-        else
-            hipLaunchKernelGGL((k_dual<1, 4>), grid, block, lds, stream, S, F, P, D, fb);
-        return hipGetLastError();
-    }
     // DET 0 (cull against the freshest hit, results timing-dependent on ~10^-10 of rays) exists only where it differs:
     // speculative traversal over quantised nodes
     const bool det = L.deterministic || !L.speculative || L.node_format == 0;
     if (L.node_format == 2) { // packed scene: speculative traversal only
-        if (!L.speculative || L.dual) return hipErrorInvalidValue;
+        if (!L.speculative) return hipErrorInvalidValue;
         if (mode == 0 && S.uv != nullptr) {
             if (det)
                 hipLaunchKernelGGL((k_persistent<0, 2, 1, 4, true, true>), grid, block, lds, stream, S, F, P, fb, ids, ts);

@@ -604,9 +604,6 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_ra
     L.node_format = effective_format(c);
     L.speculative = c->kernel_variant >= 2 ? 1 : 0;
     L.deterministic = c->deterministic;
-    L.dual = c->kernel_variant == 3 ? 1 : 0;
-    L.shade_batch = c->shade_batch;
-    L.swap_batch = c->swap_batch;
     L.leaf_batch = c->leaf_batch;
     L.primary_chunk = c->primary_chunk;
     L.occupancy = c->occupancy;
@@ -641,7 +638,7 @@ int prepare_persistent(rt_ctx *c, PersistLaunch &L, LaunchKind kind, size_t n_ra
     }
     const int rounds = std::min(std::min(want_rounds, c->ns), 63);
     // slot | round << 26 in one register; the record array is addressed through a buffer descriptor (32-bit byte offsets)
-    if (render && rounds > 1 && c->kernel_variant != 3 && slots > 0 && slots < ((size_t)1 << 26) &&
+    if (render && rounds > 1 && slots > 0 && slots < ((size_t)1 << 26) &&
         slots * kRingWords * sizeof(uint32_t) <= 0xFFFFFFFFull) {
         uint32_t *records;
         size_t record_bytes;
@@ -968,7 +965,8 @@ int rt_set_option(rt_ctx *c, int option, int64_t value) {
         if (c->shard_rank >= c->shard_world) c->shard_rank = 0;
         return RT_OK;
     case RT_OPT_KERNEL:
-        if (value < 0 || value > 3) return fail(c, RT_E_ARG, "kernel variant 0..3");
+        if (value == 3) return fail(c, RT_E_ARG, "kernel variant 3 (two paths per lane) was a measured negative and left the library (branch exp/k-dual): 0..2");
+        if (value < 0 || value > 2) return fail(c, RT_E_ARG, "kernel variant 0..2");
         c->kernel_variant = (int)value;
         return RT_OK;
     case RT_OPT_REFILL_THRESHOLD:

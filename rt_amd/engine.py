@@ -423,6 +423,11 @@ class PbrtEngine:
     def setOption(self, opt: int, value: int):
         self._check(self._lib.rt_set_option(self._h, opt, int(value)), "rt_set_option")
 
+    def getOption(self, opt: int) -> int:
+        v = C.c_int64(0)
+        self._check(self._lib.rt_get_option(self._h, opt, C.byref(v)), "rt_get_option")
+        return int(v.value)
+
     def setMaxDepth(self, d: int):
         self.setOption(OPT_MAX_DEPTH, d)
 
