@@ -3,6 +3,12 @@
 //   console                      interactive / scripted session on the default scene (needs an MI355X)
 //   console --dump-scene FILE    same loop, but `render` writes the flattened scene (148-byte records) to FILE, prints
 //                                "<n> <rand calls>" and exits: no GPU needed (tests compare it with scene_graph.py)
+//   --out FILE                   where `render` leaves its PPM (default ./output.ppm)
+//   --scene default|cat          cat = the reference's second scene, main.cpp:596-662 (rt_scene.hpp cat_scene): textured
+//                                light walls, a textured metal wall, the signature boxes; stand-in textures 0..3
+//   --camera px,py,pz,fx,fy,fz   position and front of the GL camera at start (stands in for the binary camera snapshot
+//                                the reference loads, Camera::loadSnapShot, main.cpp:663: absent)
+//   --obj NAME=FILE[:MAT]        (any number) meshes through the reference's own OBJ reader
 // Commands kept: q | m <mesh> | camera posx|negx|posy|negy|posz|negz|info|aperture x|dist_to_focus [x] |
 //                render | render -cache | render status | render param nx ny ns | render hd |
 //                mx|my|mz|rx|ry|rz|s <x> | reset | radius.    GL-only commands are accepted and ignored.
@@ -31,11 +37,40 @@ struct GlCamera { // the fields __renderScene reads (include/RT/camera.h:32-47,1
 
 int main(int argc, char **argv) {
     CountedRand rng;
-    Collection meshes = default_scene(rng);
-    // --obj NAME=FILE[:MAT] (any number, after the other options): meshes through the reference's own OBJ reader
-    for (int i = 1; i + 1 < argc; i++) {
-        if (std::string(argv[i]) != "--obj") continue;
-        const std::string spec = argv[i + 1];
+    std::string scene_name = "default", dump_path, out_file = "./output.ppm";
+    std::vector<std::string> objs;
+    GlCamera cam;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        if (i + 1 >= argc) {
+            std::cerr << "option " << a << " needs a value\n";
+            return 2;
+        }
+        const std::string v = argv[++i];
+        if (a == "--dump-scene") dump_path = v;
+        else if (a == "--out") out_file = v;
+        else if (a == "--scene") scene_name = v;
+        else if (a == "--obj") objs.push_back(v);
+        else if (a == "--camera") {
+            float f[6];
+            if (std::sscanf(v.c_str(), "%f,%f,%f,%f,%f,%f", &f[0], &f[1], &f[2], &f[3], &f[4], &f[5]) != 6) {
+                std::cerr << "--camera px,py,pz,fx,fy,fz\n";
+                return 2;
+            }
+            cam.pos = Vec3{f[0], f[1], f[2]};
+            cam.front = Vec3{f[3], f[4], f[5]};
+        } else {
+            std::cerr << "unknown option " << a << "\n";
+            return 2;
+        }
+    }
+    if (scene_name != "default" && scene_name != "cat") {
+        std::cerr << "--scene default|cat\n";
+        return 2;
+    }
+    const bool cat = scene_name == "cat";
+    Collection meshes = cat ? cat_scene() : default_scene(rng);
+    for (const std::string &spec : objs) { // NAME=FILE[:MAT]
         const size_t eq = spec.find('='), colon = spec.rfind(':');
         if (eq == std::string::npos) {
             std::cerr << "--obj NAME=FILE[:MAT]\n";
@@ -52,10 +87,10 @@ int main(int argc, char **argv) {
         }
         registerModel(meshes, std::make_shared<Mesh>(spec.substr(0, eq), v, idx, has_mat ? std::atoi(spec.c_str() + colon + 1) : 0));
     }
-    const bool dump = argc > 2 && std::string(argv[1]) == "--dump-scene";
-    const char *out_path = argc > 2 && std::string(argv[1]) == "--out" ? argv[2] : "./output.ppm";
+    const bool dump = !dump_path.empty();
+    const char *out_path = out_file.c_str();
     long long rand_calls = rng.calls; // rand() position handed to the next build
-    GlCamera cam;
+    bool scene_textures_set = !cat; // the cat scene names textures 0..3: registered before its first render
     Mesh *curr = nullptr;
     bool loop = true, texture0_set = false;
     std::string line;
@@ -111,7 +146,7 @@ int main(int argc, char **argv) {
                 }
             } else if (first == "render" && dump) {
                 std::vector<rt_triangle148> tris = gather(meshes);
-                std::ofstream(argv[2], std::ios::binary).write((const char *)tris.data(), (std::streamsize)(tris.size() * sizeof(rt_triangle148)));
+                std::ofstream(dump_path, std::ios::binary).write((const char *)tris.data(), (std::streamsize)(tris.size() * sizeof(rt_triangle148)));
                 std::cout << tris.size() << " " << rand_calls << "\n";
                 return 0;
             } else if (first == "render") {
@@ -128,6 +163,14 @@ int main(int argc, char **argv) {
                     engine.uponPixelNumChange();
                 } else {
                     const bool build = !(tokens.size() >= 2 && tokens[1] == "-cache");
+                    if (!scene_textures_set) { // stand-ins for the images the scene names (genTextures, main.cpp:715)
+                        for (int t = 0; t < 4; t++) {
+                            const std::vector<unsigned char> px = stand_in_texture(t);
+                            engine.registerTexture(t, px.data(), 64, 64);
+                        }
+                        engine.genTextures();
+                        scene_textures_set = texture0_set = true;
+                    }
                     if (build) { // main.cpp:711-713 registers every mesh of the name-sorted collection with the engine
                         std::vector<Mesh *> scene;
                         for (const auto &kv : meshes) scene.push_back(kv.second.get());

@@ -82,7 +82,7 @@ class Console:
     """One console session over one engine.  ``execute(line)`` runs one command and returns what it printed."""
 
     def __init__(self, engine, meshes=None, rand_calls: int = 0, out_path: str = "./output.ppm",
-                 snapshot_path: str = "./camera_snapshot.json"):
+                 snapshot_path: str = "./camera_snapshot.json", textures=None):
         self.engine = engine
         self.meshes = {}
         for m in (meshes or []):
@@ -97,12 +97,18 @@ class Console:
         self.last_frame = None
         self.last_triangles = None
         self._texture0_set = False
+        # images the scene names (index -> RGBA8): handed to the engine before the first render (genTextures, main.cpp:715)
+        self._scene_textures = dict(textures or {})
 
     # ---------------------------------------------------------------- render
     def _render(self, build_scene: bool, out):
         e = self.engine
         print(f"rendering a {e.nx}[width]x{e.ny}[height] image with {e.ns} samples per pixel in {e.tx}x{e.ty} blocks.",
               file=out)
+        for idx, rgba in sorted(self._scene_textures.items()):
+            e.setTexture(idx, rgba)
+            self._texture0_set = self._texture0_set or idx == 0
+        self._scene_textures = {}
         if build_scene:
             print("INFO: generate scene.", file=out)
             tris = sg.gather(self.meshes.values())
@@ -258,7 +264,8 @@ class Console:
 
 
 def main(argv=None):
-    """``python -m rt_amd.console``: the default scene (scene_graph.default_meshes) behind the console."""
+    """``python -m rt_amd.console``: the default scene (scene_graph.default_meshes) or the reference's second one
+    (``--scene cat``, scene_graph.cat_meshes) behind the console."""
     import argparse
 
     from .engine import PbrtEngine
@@ -268,14 +275,26 @@ def main(argv=None):
     ap.add_argument("--out", default="./output.ppm")
     ap.add_argument("--obj", action="append", default=[], metavar="NAME=FILE[:MAT]",
                     help="add a mesh through the reference's own OBJ reader (scene_graph.load_obj)")
+    ap.add_argument("--scene", choices=["default", "cat"], default="default",
+                    help="cat = the reference's second scene (main.cpp:596-662): textured light walls, a textured metal wall, "
+                         "the signature boxes; stand-in textures 0..3")
+    ap.add_argument("--camera", default=None, metavar="PX,PY,PZ,FX,FY,FZ",
+                    help="position and front of the GL camera at start (stands in for the binary camera snapshot the "
+                         "reference loads, main.cpp:663: absent)")
     args = ap.parse_args(argv)
-    meshes, calls = sg.default_meshes()
+    meshes, calls = sg.cat_meshes() if args.scene == "cat" else sg.default_meshes()
+    textures = {i: sg.stand_in_texture(i) for i in range(4)} if args.scene == "cat" else None
     for spec in args.obj:
         name, _, rest = spec.partition("=")
         path, _, mat = rest.rpartition(":") if ":" in rest else (rest, "", "0")
         with open(path, newline="") as fh:
             meshes.append(sg.mesh_from_obj(name, fh.read(), int(mat)))
-    con = Console(PbrtEngine(device=args.device), meshes, calls, out_path=args.out)
+    con = Console(PbrtEngine(device=args.device), meshes, calls, out_path=args.out, textures=textures)
+    if args.camera:
+        f = [float(x) for x in args.camera.split(",")]
+        if len(f) != 6:
+            ap.error("--camera PX,PY,PZ,FX,FY,FZ")
+        con.camera.position, con.camera.front = np.array(f[:3], dtype=F), np.array(f[3:], dtype=F)
     con.run()
 
 

@@ -15,6 +15,8 @@
 #include <istream>
 #include <map>
 #include <memory>
+#include <sstream>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -169,7 +171,7 @@ class Mesh {
         m = mul(m, w->m_mat4Rotation);
         return scale(m, w->m_fScale);
     }
-    Vec3 centroid() const { // resolvePosition, mesh.h:243-251 (0/0 for a mesh without vertices, as there)
+    virtual Vec3 centroid() const { // resolvePosition, mesh.h:243-251 (0/0 for a mesh without vertices, as there)
         Vec3 s;
         for (const Vec3 &v : vertices) {
             s.x += v.x;
@@ -322,6 +324,159 @@ inline MESH_PTR unit_cube_mesh(const std::string &name) {
     return std::make_shared<Mesh>(
         name, std::vector<Vec3>{{-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {1, 1, 1}, {-1, 1, 1}},
         std::vector<unsigned>{0, 2, 1, 0, 3, 2, 4, 5, 6, 4, 6, 7, 0, 1, 5, 0, 5, 4, 2, 3, 7, 2, 7, 6, 1, 2, 6, 1, 6, 5, 0, 4, 7, 0, 7, 3}, 8);
+}
+
+// The positioned overloads make_a_xy_plane(lbx, lby, rtx, rty, z, flip) / make_a_yz_plane(lbz, lby, rtz, rty, x, flip) /
+// make_a_zx_plane(lbz, lbx, rtz, rtx, y, flip) (MeshFactory.h:128-179, 232-283, 338-390): a quad between two corners in
+// the plane `at`; material 0 and no texture index until the caller sets them (the Mesh constructor's defaults).
+inline MESH_PTR positioned_plane(int kind, float a0, float b0, float a1, float b1, float c, bool flip = false) {
+    std::vector<Vec3> v;
+    if (kind == 0) // (lbx, lby, rtx, rty, z)
+        v = {{a0, b1, c}, {a0, b0, c}, {a1, b0, c}, {a1, b1, c}};
+    else if (kind == 1) // (lbz, lby, rtz, rty, x)
+        v = {{c, b1, a0}, {c, b0, a0}, {c, b0, a1}, {c, b1, a1}};
+    else // (lbz, lbx, rtz, rtx, y)
+        v = {{b1, c, a0}, {b0, c, a0}, {b0, c, a1}, {b1, c, a1}};
+    const char *names[3] = {"xy", "yz", "zx"};
+    return std::make_shared<Mesh>(std::string(names[kind]) + (flip ? "_flip" : ""), v,
+                                  flip ? std::vector<unsigned>{3, 2, 1, 3, 1, 0} : std::vector<unsigned>{0, 1, 2, 0, 2, 3}, 0,
+                                  quad_uv(flip));
+}
+
+// Six faces under one pose (mesh.h:457-535).  Every face keeps the cube as its top mesh for good, so a face's triangles
+// take the CUBE's model matrix and the CUBE's material (getMatType / getModel / isSphere look at the top mesh) --
+// setMatTypeSubMesh writes the faces' own field, which nothing reads while the top mesh is set; the texture index is
+// the face's own.
+class CubeMesh : public Mesh {
+  public:
+    CubeMesh(std::string name, MESH_PTR front, MESH_PTR back, MESH_PTR left, MESH_PTR right, MESH_PTR up, MESH_PTR bottom)
+        : Mesh(std::move(name), {}, {}), faces{std::move(front), std::move(back), std::move(left), std::move(right), std::move(up), std::move(bottom)} {
+        for (const MESH_PTR &f : faces) f->m_ptrTopMesh = this; // APPLY_TO_ALL's order, mesh.h:492-497
+    }
+    void setMatTypeSubMesh(int m) {
+        for (const MESH_PTR &f : faces) f->matType = m;
+    }
+    void genTriangles(std::vector<rt_triangle148> &out) const override {
+        for (const MESH_PTR &f : faces) f->genTriangles(out);
+    }
+    Vec3 centroid() const override { // resolvePosition, mesh.h:511-522: the mean of the six faces' vertex means
+        Vec3 s;
+        for (const MESH_PTR &f : faces) {
+            const Vec3 c = f->centroid();
+            s.x += c.x;
+            s.y += c.y;
+            s.z += c.z;
+        }
+        return Vec3{s.x / 6.0f, s.y / 6.0f, s.z / 6.0f};
+    }
+    void shareMeshData(Mesh &target) const { // mesh.h:165-179, 524-526: vertices and re-based indices; no pose travels
+        for (const MESH_PTR &f : faces) {
+            const unsigned base = (unsigned)target.vertices.size();
+            target.vertices.insert(target.vertices.end(), f->vertices.begin(), f->vertices.end());
+            target.texcoords.insert(target.texcoords.end(), f->texcoords.begin(), f->texcoords.end());
+            for (unsigned i : f->indices) target.indices.push_back(i + base);
+        }
+    }
+    std::vector<MESH_PTR> faces;
+};
+
+// make_a_cube_mesh(lb, rt, ry, translation, _setup), MeshFactory.h:392-421
+inline std::shared_ptr<CubeMesh> make_a_cube_mesh(Vec3 lb, Vec3 rt, float ry, Vec3 translation, const std::string &name = "None") {
+    auto cube = std::make_shared<CubeMesh>(name, positioned_plane(0, lb.x, lb.y, rt.x, rt.y, rt.z, false),
+                                           positioned_plane(0, lb.x, lb.y, rt.x, rt.y, lb.z, true),
+                                           positioned_plane(1, lb.z, lb.y, rt.z, rt.y, lb.x, false),
+                                           positioned_plane(1, lb.z, lb.y, rt.z, rt.y, rt.x, true),
+                                           positioned_plane(2, lb.z, lb.x, rt.z, rt.x, rt.y, false),
+                                           positioned_plane(2, lb.z, lb.x, rt.z, rt.x, lb.y, true));
+    cube->rotationCommand(1, ry);
+    cube->translateXCommand(translation.x);
+    cube->translateYCommand(translation.y);
+    cube->translateZCommand(translation.z);
+    for (const MESH_PTR &f : cube->faces) f->texIdx = 3;
+    return cube;
+}
+
+// Stand-in for .\\cache\\cube_locations.txt (absent): first line the cubes' footprint, then "z x" per cube -- the letters
+// R and T on a 5 x 7 dot matrix (the same text as scene_graph.py's SIGNATURE_LOCATIONS).
+inline std::string signature_locations() {
+    const char *rows[5] = {"1110.11111", "1001.00100", "1110.00100", "1010.00100", "1001.00100"};
+    std::string t = "60\n";
+    for (int row = 0; row < 5; row++)
+        for (int col = 0; rows[row][col]; col++)
+            if (rows[row][col] == '1') t += std::to_string(-150 + 75 * row) + " " + std::to_string(-460 + 75 * col) + "\n";
+    return t;
+}
+// signature_reader, main.cpp:334-369.  r stands for the reference's rand() / RAND_MAX after srand(time(nullptr)): a
+// parameter here; the process's rand() sequence is not reseeded.
+inline MESH_PTR signature_mesh(const std::string &text, double r = 0.5) {
+    std::istringstream in(text);
+    std::string line;
+    std::getline(in, line);
+    const float width = std::stof(line);
+    auto list = std::make_shared<Mesh>("meshList", std::vector<Vec3>{}, std::vector<unsigned>{});
+    const float hw = width / 2.5;
+    const float h = width * (r * 2.0f + 1.0);
+    while (std::getline(in, line)) {
+        std::istringstream iss(line);
+        std::vector<float> v;
+        for (std::string t; iss >> t;) v.push_back(std::stof(t));
+        if (v.empty()) continue;
+        if (v.size() != 2) throw std::runtime_error("failed in signature reader.");
+        const float z = v[0], x = v[1];
+        make_a_cube_mesh(Vec3{x - hw, 0, z - hw}, Vec3{x + hw, h, z + hw}, 0.0f, Vec3{0, 0, 0})->shareMeshData(*list);
+    }
+    return list;
+}
+
+// stand-ins for the four images the textured scene names (absent): n x n RGBA8, integers only (scene_graph.py's
+// stand_in_texture): 0 the checkerboard above, 1 vertical stripes, 2 a two-way gradient, 3 a grid of dots
+inline std::vector<unsigned char> stand_in_texture(int index, int n = 64) {
+    if (index == 0) return default_texture(n);
+    std::vector<unsigned char> t((size_t)n * n * 4);
+    for (int j = 0; j < n; j++)
+        for (int i = 0; i < n; i++) {
+            unsigned char *p = &t[4 * ((size_t)j * n + i)];
+            if (index == 1) {
+                const bool on = ((i * 8 / n) % 2) == 0;
+                p[0] = on ? 200 : 60, p[1] = on ? 180 : 90, p[2] = on ? 60 : 200;
+            } else if (index == 2) {
+                p[0] = (unsigned char)(i * 255 / (n - 1)), p[1] = (unsigned char)(j * 255 / (n - 1)), p[2] = 128;
+            } else {
+                const bool on = ((i * 8) % n) * 2 < n && ((j * 8) % n) * 2 < n;
+                p[0] = on ? 250 : 90, p[1] = on ? 240 : 140, p[2] = on ? 200 : 90;
+            }
+            p[3] = 255;
+        }
+    return t;
+}
+
+// The reference's second scene, the `#ifdef CAT` block of main() (main.cpp:596-662); see scene_graph.py's cat_meshes
+// for the stand-ins.  Consumes no rand() call.
+inline Collection cat_scene(double r = 0.5) {
+    Collection col;
+    auto box02 = make_a_cube_mesh(Vec3{0, 0, 0}, Vec3{800, 450, 450}, 15, Vec3{0, 0, 0}, "box02");
+    box02->setMatTypeSubMesh(3); // LIGHT -- on the faces' own field, which the cube's material (0) overrides
+    registerModel(col, box02);
+    MESH_PTR s1 = unit_cube_mesh("s1"); // Model("models/sphere.obj", "s1"): material 5, flagged as a sphere
+    s1->matType = 5;
+    s1->m_bIsSphere = true;
+    registerModel(col, s1);
+    const float height = 800;
+    auto named = [&](MESH_PTR m, const char *name, int mat, int tex) {
+        m->m_strName = name;
+        m->matType = mat;
+        m->texIdx = tex;
+        registerModel(col, m);
+    };
+    named(positioned_plane(1, -1000, 0, 1000, height, -1000, true), "left_wall", 4, 1);
+    named(positioned_plane(1, -1000, 0, 1000, height, 1000), "right_wall", 3, 2);
+    named(positioned_plane(0, -1000, 0, 1000, height, -1000), "back_wall", 3, 0);
+    registerModel(col, light_mesh());
+    MESH_PTR m = signature_mesh(signature_locations(), r);
+    m->matType = 6; // METAL
+    registerModel(col, m);
+    named(positioned_plane(2, -1000, -1000, 1000, 1000, 0, false), "floor", 0, -1); // setMatType(10), then setMatType(0)
+    return col;
 }
 
 // rand() as the reference uses it, counted: the builder continues the same sequence (rt_build_bvh's second argument)

@@ -354,6 +354,166 @@ def unit_cube_mesh(name: str = "cube") -> Mesh:
     return Mesh(name, v, idx, mat_type=8)
 
 
+def positioned_plane(kind: str, lb_a: float, lb_b: float, rt_a: float, rt_b: float, at: float, flip: bool = False) -> Mesh:
+    """The positioned overloads make_a_xy_plane(lbx, lby, rtx, rty, z, flip) / make_a_yz_plane(lbz, lby, rtz, rty, x,
+    flip) / make_a_zx_plane(lbz, lbx, rtz, rtx, y, flip) (MeshFactory.h:128-179, 232-283, 338-390): a quad between two
+    corners in the plane `at`; named "xy" / "yz" / "zx" (+ "_flip") until the caller renames it; material 0 and no
+    texture index until the caller sets them (the Mesh constructor's defaults, mesh.h:70-71)."""
+    a0, b0, a1, b1, c = F(lb_a), F(lb_b), F(rt_a), F(rt_b), F(at)
+    if kind == "xy":    # (lbx, lby, rtx, rty, z)
+        v = [[a0, b1, c], [a0, b0, c], [a1, b0, c], [a1, b1, c]]
+    elif kind == "yz":  # (lbz, lby, rtz, rty, x)
+        v = [[c, b1, a0], [c, b0, a0], [c, b0, a1], [c, b1, a1]]
+    elif kind == "zx":  # (lbz, lbx, rtz, rtx, y)
+        v = [[b1, c, a0], [b0, c, a0], [b0, c, a1], [b1, c, a1]]
+    else:
+        raise ValueError("plane kind must be xy, yz or zx")
+    idx = [3, 2, 1, 3, 1, 0] if flip else [0, 1, 2, 0, 2, 3]
+    return Mesh(kind + ("_flip" if flip else ""), v, idx, mat_type=0, tex_idx=-1, texcoords=_FLIP_UV if flip else _UV)
+
+
+class CubeMesh(Mesh):
+    """Six faces under one pose (mesh.h:457-535).  Every face keeps the cube as its top mesh for good, so a face's
+    triangles take the CUBE's model matrix and the CUBE's material (getMatType / getModel / isSphere look at the top
+    mesh, mesh.h:104-144, 278-281) -- setMatTypeSubMesh writes the faces' own field, which nothing reads while the
+    top mesh is set; the texture index is the face's own."""
+
+    def __init__(self, front: Mesh, back: Mesh, left: Mesh, right: Mesh, up: Mesh, bottom: Mesh, name: str = "None"):
+        super().__init__(name, np.zeros((0, 3), dtype=F), [], 0)
+        self.faces = [front, back, left, right, up, bottom]  # APPLY_TO_ALL's order (mesh.h:492-497)
+        for f in self.faces:
+            f.top = self
+
+    def set_mat_type_sub_mesh(self, m: int):
+        for f in self.faces:
+            f.mat_type = m
+
+    def gen_triangles(self) -> np.ndarray:
+        return np.concatenate([f.gen_triangles() for f in self.faces])
+
+    def centroid(self) -> np.ndarray:
+        """resolvePosition (mesh.h:511-522): the mean of the six faces' vertex means."""
+        acc = np.zeros(3, dtype=F)
+        for f in self.faces:
+            acc = (acc + f.centroid()).astype(F)
+        return (acc / F(6.0)).astype(F)
+
+    def share_mesh_data(self, target: Mesh):
+        """shareMeshData (mesh.h:165-179, 524-526): every face appends its vertices and (re-based) indices to
+        `target`; the cube's pose does not travel."""
+        for f in self.faces:
+            base = target.vertices.shape[0]
+            target.vertices = np.concatenate([target.vertices, f.vertices]).astype(F)
+            target.texcoords = np.concatenate([target.texcoords, f.texcoords]).astype(F)
+            target.indices = np.concatenate([target.indices, f.indices + base])
+
+
+def make_a_cube_mesh(lb, rt, ry: float, translation, name: str = "None") -> CubeMesh:
+    """make_a_cube_mesh(lb, rt, ry, translation, _setup) (MeshFactory.h:392-421): six positioned planes between the
+    corners lb and rt, the back / right / bottom ones flipped, rotated by ry degrees about y and translated as ONE
+    body; every face names texture 3."""
+    front = positioned_plane("xy", lb[0], lb[1], rt[0], rt[1], rt[2], False)
+    back = positioned_plane("xy", lb[0], lb[1], rt[0], rt[1], lb[2], True)
+    left = positioned_plane("yz", lb[2], lb[1], rt[2], rt[1], lb[0], False)
+    right = positioned_plane("yz", lb[2], lb[1], rt[2], rt[1], rt[0], True)
+    top = positioned_plane("zx", lb[2], lb[0], rt[2], rt[0], rt[1], False)
+    bottom = positioned_plane("zx", lb[2], lb[0], rt[2], rt[0], lb[1], True)
+    cube = CubeMesh(front, back, left, right, top, bottom, name)
+    cube.rotation_command(1, ry)
+    cube.translate_command(*[float(t) for t in translation])
+    for f in cube.faces:
+        f.tex_idx = 3
+    return cube
+
+
+# Stand-in for .\\cache\\cube_locations.txt (absent, like every file under the reference's cache directory): the first
+# line is the cubes' footprint, every other line "z x" of one cube -- here the letters R and T on a 5 x 7 dot matrix.
+SIGNATURE_LOCATIONS = "60\n" + "".join(
+    f"{-150 + 75 * row} {-460 + 75 * col}\n"
+    for row, bits in enumerate(("1110.11111", "1001.00100", "1110.00100", "1010.00100", "1001.00100"))
+    for col, ch in enumerate(bits) if ch == "1")
+
+
+def signature_mesh(text: str = SIGNATURE_LOCATIONS, r: float = 0.5) -> Mesh:
+    """signature_reader (main.cpp:334-369): one box per "z x" line, footprint width / 2.5 either side, all of one
+    height width * (2 r + 1), their faces' vertices shared into ONE mesh "meshList" (so the boxes lose their own
+    pose objects; they were made with none).  `r` stands for the reference's `rand() / RAND_MAX` right after
+    `srand(time(nullptr))`, which no restatement can reproduce: it is a parameter here, and the session's rand()
+    sequence is NOT reseeded (the builder continues the unseeded sequence, as for the default scene)."""
+    lines = text.split("\n")
+    width = F(float(lines[0]))
+    locations = []
+    for line in lines[1:]:
+        v = [F(float(t)) for t in line.split()]
+        if not line.strip():
+            continue  # getline's last, empty line
+        if len(v) != 2:
+            raise ValueError("failed in signature reader.")
+        locations.append((v[0], v[1]))
+    mesh_list = Mesh("meshList", np.zeros((0, 3), dtype=F), [], 0)
+    hw = F(float(width) / 2.5)                       # float hw = width / 2.5;
+    h = F(float(width) * (float(r) * 2.0 + 1.0))     # float h = width * (r * 2.0f + 1.0);   r is a double
+    for z, x in locations:
+        box = make_a_cube_mesh((F(x - hw), F(0), F(z - hw)), (F(x + hw), h, F(z + hw)), 0.0, (0.0, 0.0, 0.0))
+        box.share_mesh_data(mesh_list)
+    return mesh_list
+
+
+def stand_in_texture(index: int, n: int = 64) -> np.ndarray:
+    """Stand-ins for the four images the reference's textured scene names (texture units 0..3; the files are absent):
+    n x n RGBA8, integers only, one recognisable pattern each -- 0 the checkerboard of default_texture, 1 vertical
+    stripes, 2 a two-way gradient, 3 a grid of dots."""
+    if index == 0:
+        return default_texture(n)
+    i = np.arange(n)
+    jj, ii = np.meshgrid(i, i, indexing="ij")  # jj = row, ii = column
+    t = np.zeros((n, n, 4), dtype=np.uint8)
+    if index == 1:
+        on = ((ii * 8) // n) % 2 == 0
+        t[..., 0], t[..., 1], t[..., 2] = np.where(on, 200, 60), np.where(on, 180, 90), np.where(on, 60, 200)
+    elif index == 2:
+        t[..., 0], t[..., 1], t[..., 2] = (ii * 255) // (n - 1), (jj * 255) // (n - 1), 128
+    elif index == 3:
+        on = (((ii * 8) % n) * 2 < n) & (((jj * 8) % n) * 2 < n)
+        t[..., 0], t[..., 1], t[..., 2] = np.where(on, 250, 90), np.where(on, 240, 140), np.where(on, 200, 90)
+    else:
+        raise ValueError("stand-in textures 0..3")
+    t[..., 3] = 255
+    return t
+
+
+def cat_meshes(r: float = 0.5, locations: str = SIGNATURE_LOCATIONS):
+    """The reference's second scene, the `#ifdef CAT` block of main() (main.cpp:596-662): a textured box whose faces
+    name texture 3, one sphere, a textured metal wall (material 4, texture 1), two textured LIGHT walls (textures 2
+    and 0), the ceiling light, the signature boxes in metal and a floor.  Stand-ins where the reference's files are
+    absent: models/sphere.obj -> the sphere-flagged unit cube (as for the default scene), cache\\cube_locations.txt ->
+    SIGNATURE_LOCATIONS, the images -> stand_in_texture(0..3), every pose file -> scale 1, the camera snapshot -> the
+    console's --camera.  Returns (meshes in registration order, rand() calls consumed = 0)."""
+    meshes = []
+    box02 = make_a_cube_mesh((0, 0, 0), (800, 450, 450), 15, (0, 0, 0), "box02")
+    box02.set_mat_type_sub_mesh(3)  # LIGHT -- on the faces' own field, which the cube's material (0) overrides
+    meshes.append(box02)
+    s1 = unit_cube_mesh("s1")  # Model("models/sphere.obj", "s1"): material 5, flagged as a sphere
+    s1.mat_type = 5
+    s1.is_sphere = True
+    meshes.append(s1)
+    height = 800
+    left_wall = positioned_plane("yz", -1000, 0, 1000, height, -1000, True)
+    left_wall.name, left_wall.mat_type, left_wall.tex_idx = "left_wall", 4, 1
+    right_wall = positioned_plane("yz", -1000, 0, 1000, height, 1000)
+    right_wall.name, right_wall.mat_type, right_wall.tex_idx = "right_wall", 3, 2
+    back_wall = positioned_plane("xy", -1000, 0, 1000, height, -1000)
+    back_wall.name, back_wall.mat_type, back_wall.tex_idx = "back_wall", 3, 0
+    meshes += [left_wall, right_wall, back_wall, light_mesh()]
+    m = signature_mesh(locations, r)
+    m.mat_type = 6  # METAL
+    meshes.append(m)
+    floor = positioned_plane("zx", -1000, -1000, 1000, 1000, 0, False)
+    floor.name, floor.mat_type = "floor", 0  # setMatType(10), then setMatType(0)
+    meshes.append(floor)
+    return meshes, 0
+
+
 def default_meshes():
     """main.cpp:408-500 restated (see the module docstring for what is assumed).  Returns (meshes, rand_calls):
     the registered meshes in registration order and the number of rand() calls the scene setup consumed."""

@@ -441,6 +441,49 @@ def test_cpp_console_session_equals_the_python_one(oracle, tmp_path):
     eng.close()
 
 
+def test_cat_scene_consoles_agree_and_equal_the_oracle(oracle, tmp_path):
+    """The reference's second scene (`#ifdef CAT`, main.cpp:596-662) through both consoles (`--scene cat`): textured
+    LIGHT walls (material.h:140-146 reads the texture for the emission), a metal wall that names a texture, the
+    rotated box whose faces take the cube's pose and material, the signature boxes in metal.  Same scripted session --
+    camera from the command line (the snapshot's stand-in), a posed box, a second build, a cached render with a lens --
+    same output.ppm byte for byte; the last frame is also the oracle's."""
+    import subprocess
+
+    from rt_amd import console as rc
+    from rt_amd import scene_graph as sg
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "console")
+    if not os.path.exists(exe):
+        pytest.fail("examples/console is not built: run __graft_entry__.build()")
+    camera = "-500,350,900,0.6,-0.2,-0.75"
+    script = ["render param 96 54 4", "render", "m box02", "ry 30", "mx -150", "m s1", "s 90", "my 250", "mz 300", "render",
+              "camera aperture 4", "camera dist_to_focus", "render -cache", "q"]
+    out = subprocess.run([exe, "--scene", "cat", "--camera", camera], input="\n".join(script) + "\n", cwd=tmp_path,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.count("PbrtEngine: rendering finished.") == 3 and "Console Error" not in out.stdout
+    meshes, calls = sg.cat_meshes()
+    eng = rt_amd.PbrtEngine(device=0)
+    con = rc.Console(eng, meshes, calls, out_path=str(tmp_path / "py.ppm"), textures={i: sg.stand_in_texture(i) for i in range(4)})
+    f = [float(x) for x in camera.split(",")]
+    con.camera.position, con.camera.front = np.array(f[:3], np.float32), np.array(f[3:], np.float32)
+    for line in script:
+        assert "Console Error" not in con.execute(line)
+    assert (tmp_path / "output.ppm").read_bytes() == (tmp_path / "py.ppm").read_bytes()
+    tris = con.last_triangles
+    assert sorted(np.unique(tris["texIdx"]).tolist()) == [-1, 0, 1, 2, 3]
+    for i in range(4):
+        oracle.set_texture(i, sg.stand_in_texture(i))
+    nodes = oracle.build_bvh(tris, calls + sg.build_rand_calls(int(tris.shape[0])))  # second build of the session
+    assert nodes.tobytes() == eng.getBvhNodes().tobytes()
+    c = con.camera
+    ocam = oracle.camera(c.position, c.position + c.front, 40.0, 96 / 54, float(c.aperture), float(c.dist_to_focus))
+    fb_o, _ = oracle.render(tris, nodes, oracle.material_table(), ocam, 96, 54, 4, 50, mode=1)
+    assert con.last_frame.tobytes() == fb_o.tobytes()
+    assert len(np.unique(con.last_frame)) > 50  # a picture, not a flat colour
+    eng.close()
+
+
 @pytest.mark.parametrize("thr,n,qw", [(48, 100000, 24), (64, 777, 24), (1, 5000, 1), (48, 1, 24), (48, 600000, 32)])
 def test_trace_rays_device_equals_host_path_and_oracle(oracle, thr, n, qw):
     """rt_trace_rays_device (rays and results in device memory, persistent waves with per-lane refill) against

@@ -282,6 +282,68 @@ def test_cpp_scene_code_matches_this_one(tmp_path):
         assert dump.read_bytes() == tris.tobytes()
 
 
+def test_cat_scene_shape_order_and_cpp_agreement(tmp_path):
+    """The reference's second scene (main.cpp:596-662; scene_graph.cat_meshes / rt_scene.hpp cat_scene): "light" first,
+    then the name-sorted rest; the box's faces carry the CUBE's material (0: setMatTypeSubMesh(LIGHT) writes a field the
+    top mesh overrides) and pose (15 degrees about y) but their own texture index 3; the signature boxes arrive as ONE
+    metal mesh without texture; textured LIGHT walls and the textured metal wall keep their indices.  The C++
+    restatement leaves the same records, byte for byte, also after posing the box and the signature."""
+    import os
+    import subprocess
+
+    meshes, calls = sg.cat_meshes()
+    assert calls == 0 and [m.name for m in meshes] == ["box02", "s1", "left_wall", "right_wall", "back_wall", "light", "meshList", "floor"]
+    tris = sg.gather(meshes)
+    n_boxes = sg.SIGNATURE_LOCATIONS.count("\n") - 1
+    # light (2) | back_wall (2) | box02 (12) | floor (2) | left_wall (2) | meshList | right_wall (2) | s1 (1 sphere)
+    assert tris.shape[0] == 2 + 2 + 12 + 2 + 2 + 12 * n_boxes + 2 + 1
+    assert (tris["matType"][:2] == 3).all() and (tris["texIdx"][:2] == -1).all()
+    back, box, floor, left = tris[2:4], tris[4:16], tris[16:18], tris[18:20]
+    sig, right, s1 = tris[20:20 + 12 * n_boxes], tris[-3:-1], tris[-1]
+    assert (back["matType"] == 3).all() and (back["texIdx"] == 0).all()
+    assert (box["matType"] == 0).all() and (box["texIdx"] == 3).all()
+    assert (floor["matType"] == 0).all() and (floor["texIdx"] == -1).all()
+    assert (left["matType"] == 4).all() and (left["texIdx"] == 1).all()
+    assert (sig["matType"] == 6).all() and (sig["texIdx"] == -1).all()
+    assert (right["matType"] == 3).all() and (right["texIdx"] == 2).all()
+    assert s1["shapeType"] == 1 and s1["matType"] == 5 and tris["shapeType"].sum() == 1
+    # the box is rotated as one body: its front face (z = 450 before the pose) is no longer axis-aligned, y is untouched
+    front_z = np.concatenate([box[k][:2, 2] for k in ("v0", "v1", "v2")])
+    assert len(np.unique(front_z)) > 1 and set(np.unique(box["v0"][:, 1]).tolist()) <= {0.0, 450.0}
+    assert sig["v0"][:, 1].max() == np.float32(60 * (0.5 * 2.0 + 1.0))  # every signature box has the one height
+    # quads carry the factory's texture coordinates (flipped faces mirrored)
+    assert set(np.unique(tris["u"]).tolist()) == {0.0, 1.0}
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "console")
+    if not os.path.exists(exe):
+        pytest.skip("examples/console is not built: run __graft_entry__.build()")
+    poses = ["m box02", "ry -40", "mx 120.5", "s 0.5", "m meshList", "rz 3", "my 2", "m s1", "s 80", "my 200", "m left_wall", "mx 10"]
+    for script in ([], poses):
+        dump = tmp_path / "cat.bin"
+        out = subprocess.run([exe, "--scene", "cat", "--dump-scene", str(dump)], input="\n".join(script + ["render"]) + "\n",
+                             capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0, out.stderr
+        meshes, calls = sg.cat_meshes()
+
+        class NoEngine:
+            def setTexture(self, idx, rgba):
+                pass
+
+        con = rc.Console(NoEngine(), meshes, calls, out_path=None)
+        for line in script:
+            assert "Error" not in con.execute(line)
+        want = sg.gather(con.meshes.values())
+        assert [int(x) for x in out.stdout.replace(">>>:", " ").split()[-2:]] == [want.shape[0], 0]
+        assert dump.read_bytes() == want.tobytes()
+
+
+def test_stand_in_textures_are_distinct():
+    t = [sg.stand_in_texture(i) for i in range(4)]
+    assert all(x.shape == (64, 64, 4) and x.dtype == np.uint8 and (x[..., 3] == 255).all() for x in t)
+    assert len({x.tobytes() for x in t}) == 4
+    with pytest.raises(ValueError):
+        sg.stand_in_texture(4)
+
+
 OBJ = """# a tetrahedron and a quad
 v 0 0 0
 v 1.5 0 0
