@@ -105,23 +105,29 @@ def cpu_baseline_and_bytes(tris, nodes, cam_args, nx, ny, ns, depth, stride, thr
     return base, bytes_per_ray, fb_ref[sub].copy()
 
 
-PROFILE_ROUND = "r02"  # profiles/<round>_pmc_summary.json, <round>_lane_occupancy.jsonl: refreshed by tools/pmc_passes.sh
+PROFILE_ROUND = "r03"  # profiles/<round>_pmc_summary[_<workload>].json, <round>_lane_occupancy.jsonl: tools/profile_round.sh
 SIMDS = 1024           # 256 CUs x 4
 PEAK_CLOCK_HZ = 2.4e9  # MI355X_MICROARCH.md, chip-level parameters
 VALU_ISSUE_CYCLES = 2  # cycles a SIMD needs per wave64 VALU instruction (same guide, wave scheduling)
 
 
 def committed_profile(workload_key):
-    """What the committed rocprofv3 passes say about the render kernel (tools/pmc_passes.sh -> tools/pmc_summary.py;
-    tools/trav_stats.py for the analysis build's per-ray counts).  These are NOT measured in this run: the record
-    carries the hash of the kernel sources it was taken from, and `profile_stale` says when they have changed since."""
+    """What the committed rocprofv3 passes say about the render kernel ON THIS WORKLOAD (tools/pmc_passes.sh ->
+    tools/pmc_summary.py; tools/trav_stats.py for the analysis build's per-ray counts): profiles/<round>_pmc_summary_
+    <workload>.json when there is one, else profiles/<round>_pmc_summary.json (the bench workload).  These are NOT
+    measured in this run: the record carries the hash of the kernel sources it was taken from, and `profile_stale`
+    says when they have changed since."""
     from tools import profile_hash
 
-    out = {"source": f"profiles/{PROFILE_ROUND}_pmc_summary.json", "profile_stale": True}
+    name = f"{PROFILE_ROUND}_pmc_summary_{workload_key}.json"
+    if not os.path.exists(os.path.join(ROOT, "profiles", name)):
+        name = f"{PROFILE_ROUND}_pmc_summary.json"
+    out = {"source": f"profiles/{name}", "profile_stale": True}
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_summary.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
         out["profile_stale"] = d.get("_meta", {}).get("source_hash") != profile_hash.kernel_source_hash()
-        k = [x for x in d if "k_persistent<0, 1, 1, 6" in x][0]
+        k = [x for x in d if "k_persistent<0," in x][0]  # the render instance that ran
+        out["kernel"] = k.replace("void rtamd::", "")
         v = {c: x["per_dispatch"] for c, x in d[k].items()}
         out["valu_insts_per_launch"] = v["SQ_INSTS_VALU"]
         out["cycles_per_launch"] = v["GRBM_GUI_ACTIVE"] / 8.0  # the counter sums the 8 XCDs
@@ -136,7 +142,6 @@ def committed_profile(workload_key):
             out["fabric_bytes_per_launch"] = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
             out["fabric_write_bytes_per_launch"] = v["WRITE_SIZE"] * 1024.0
         # the vector-memory data path of a CU (TA -> TCP = L1 -> TD): busy shares, and L1 tag accesses per cycle and CU
-        # (one 64-byte access per cycle is what the L1 takes: 256 CUs x 64 B x 2.4 GHz = 39.3 TB/s)
         if "TCP_TOTAL_CACHE_ACCESSES_sum" in v:
             out["l1_accesses_per_launch"] = v["TCP_TOTAL_CACHE_ACCESSES_sum"]
             out["l1_accesses_per_cycle_per_cu"] = v["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / out["cycles_per_launch"]
@@ -150,12 +155,98 @@ def committed_profile(workload_key):
     try:
         for line in open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_lane_occupancy.jsonl")):
             t = json.loads(line)
-            if t.get("workload") == workload_key:
+            if t.get("workload") == workload_key and "node_visits_per_ray" in t:
                 out["node_visits_per_ray"] = t["node_visits_per_ray"]
                 out["prim_tests_per_ray"] = t["prim_tests_per_ray"]
     except Exception:  # noqa: BLE001
         pass
     return out
+
+
+def roofline_of(prof, workload_key, world, kernel_s, rays_per_launch, bytes_per_ray):
+    """The `roofline` object of the line.  Three units are priced, each from the committed counter pass of THESE sources
+    on THIS workload over this run's own kernel time (no fraction is claimed from counters of other code or another
+    scene), and the headline `bound` is the one the evidence says binds:
+      valu_issue  wave64 vector instructions per launch against 1024 SIMDs x 2.4 GHz / 2 cycles -- what binds the
+                  bench frame: the A/B of node formats (profiles/r03_ab_node_format*) took 19 % of the L1 accesses away
+                  for 6 % more vector instructions and the frame got 1.5 % SLOWER;
+      hbm         the L2s' fabric traffic against 8 TB/s (an upper bound on HBM bytes: Infinity-Cache hits included)
+                  -- what binds scenes far beyond the caches (BASELINE config 5);
+      vector_l1   L1 tag accesses x 64 B against one access per cycle and CU -- near its ceiling on the bench frame and,
+                  by the same A/B, not what the frame waits for; reported with the share of each touched line a lane
+                  uses (16 of 128 bytes), which is where the waste is."""
+    same_workload = prof.get("workload") == workload_key and world == 1 and not prof.get("profile_stale", True)
+    roof = {"kernel": prof.get("kernel", "k_persistent<0, 1, 1, 6, false, true>") + " (render: quantized 4-wide nodes, speculative traversal, rounds)",
+            "kernel_ms": kernel_s * 1e3, "rays_per_launch": rays_per_launch, "committed_profile": prof}
+    L1_PEAK_GBS = 256 * 64 * PEAK_CLOCK_HZ / 1e9
+    mem = {"hbm_peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    if "node_visits_per_ray" in prof:
+        dev_bytes = 64.0 * prof["node_visits_per_ray"] + 48.0 * prof["prim_tests_per_ray"] + 36.0
+        mem.update({"device_bytes_per_ray": dev_bytes, "device_bytes_rate_gbs": dev_bytes * rays_per_launch / kernel_s / 1e9,
+                    "device_bytes_note": "64 B per wide-node visit + 48 B per primitive test + 28 B ray in + 8 B hit out, counts from the analysis build",
+                    "node_visits_per_ray": prof["node_visits_per_ray"], "prim_tests_per_ray": prof["prim_tests_per_ray"]})
+    if bytes_per_ray is not None:
+        mem["algorithmic_bytes_per_ray_binary_tree"] = bytes_per_ray
+        mem["binary_tree_rate_gbs"] = bytes_per_ray * rays_per_launch / kernel_s / 1e9
+        mem["binary_tree_note"] = "SURVEY 8d's model (32 B per box test of an ordered walk of the reference's BINARY tree); it does not describe this kernel, which visits ~16 wide nodes per ray, not ~570 boxes"
+    roof["hbm"] = mem
+    roof["traffic"] = None
+    if not (same_workload and "valu_insts_per_launch" in prof):
+        roof.update({"bound": "valu_issue", "achieved": None, "peak": SIMDS * PEAK_CLOCK_HZ / VALU_ISSUE_CYCLES / 1e9,
+                     "unit": "G wave64-inst/s", "frac": None, "profile_stale": bool(prof.get("profile_stale", True)),
+                     "note": "no committed counter pass of these sources for this workload / rank count (profile_stale: the "
+                             "kernel sources changed since the pass in profiles/ was taken): no fraction is claimed"})
+        return roof
+    achieved = prof["valu_insts_per_launch"] / kernel_s / 1e9
+    peak = SIMDS * PEAK_CLOCK_HZ / VALU_ISSUE_CYCLES / 1e9
+    valu = {"achieved": achieved, "peak": peak, "unit": "G wave64-inst/s", "frac": achieved / peak,
+            "basis": "SQ_INSTS_VALU per launch / kernel time; 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction",
+            "lane_utilisation": prof.get("lane_utilisation"),
+            "useful_lane_frac": achieved / peak * prof.get("lane_utilisation", 0.0),
+            "waves_per_simd": prof.get("waves_per_simd")}
+    # against what a SIMD was MEASURED to issue (tools/micro/valu_rate.hip, 8 waves per SIMD): independent v_fma_f32, and
+    # the node test's own instruction mix -- the practical ceilings under the 2-cycle specification
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "r02_valu_issue_rate.jsonl")):
+            t = json.loads(line)
+            if t.get("waves_per_simd") == 8 and t.get("kind") in ("v_fma_f32", "node-test mix"):
+                key = "frac_of_measured_fma_rate" if t["kind"] == "v_fma_f32" else "frac_of_measured_node_mix_rate"
+                valu[key] = achieved / (SIMDS * PEAK_CLOCK_HZ / t["cycles_per_wave64_inst"] / 1e9)
+    except Exception:  # noqa: BLE001
+        pass
+    roof["valu_issue"] = valu
+    if "l1_accesses_per_launch" in prof:
+        a = prof["l1_accesses_per_launch"] * 64.0 / kernel_s / 1e9
+        roof["vector_l1"] = {
+            "achieved": a, "peak": L1_PEAK_GBS, "unit": "GB/s", "frac": a / L1_PEAK_GBS,
+            "basis": "TCP_TOTAL_CACHE_ACCESSES x 64 B per launch / kernel time; peak = one L1 line access per cycle and CU x 256 CUs "
+                     "x 2.4 GHz, the ceiling tools/micro/l1_rate.hip measures (profiles/r02_l1_rate.jsonl).  A tag-rate occupancy, "
+                     "not a data rate: each access hands ONE lane 16 bytes",
+            "data_delivered_gbs": prof["l1_accesses_per_launch"] * 16.0 / kernel_s / 1e9,
+            "useful_l1_bytes_frac": 16.0 / 128.0,  # bytes a lane takes from each 128-byte line it touches
+            "binds": False,
+            "binds_evidence": "RT_OPT_NODE_FORMAT 2 (three loads per node visit): L1 accesses -19 %, vector instructions +6 %, frame "
+                              "+1.5 % (profiles/r03_ab_node_format.log, r03_ab_node_format{1,2}_pmc_summary.json)",
+            "accesses_per_cycle_per_cu_at_measured_clock": prof.get("l1_accesses_per_cycle_per_cu"),
+            "td_busy_frac": prof.get("td_busy_frac"), "ta_busy_frac": prof.get("ta_busy_frac"),
+            "l1_hit_rate": prof.get("l1_hit_rate"), "l2_hit_rate": prof.get("l2_hit_rate")}
+    hbm_frac = None
+    if "fabric_bytes_per_launch" in prof:
+        mem["fabric_traffic_bytes_per_launch"] = prof["fabric_bytes_per_launch"]
+        mem["fabric_traffic_gbs"] = prof["fabric_bytes_per_launch"] / kernel_s / 1e9
+        hbm_frac = mem["fabric_traffic_gbs"] / HBM_PEAK_GBS
+        mem["frac"] = hbm_frac
+        mem["frac_note"] = "(2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction) / kernel time / 8 TB/s: the L2s' fabric requests, Infinity-Cache hits included -- an UPPER bound on the HBM fraction"
+        if "device_bytes_per_ray" in mem:  # > 1: lines fetched and not used; < 1: the caches absorb the rest
+            mem["traffic_over_device_bytes"] = prof["fabric_bytes_per_launch"] / (mem["device_bytes_per_ray"] * rays_per_launch)
+        roof["traffic"] = prof["fabric_bytes_per_launch"]
+    # the headline: HBM where the scene streams from it, vector-instruction issue otherwise (vector_l1: see above)
+    v_frac = valu.get("frac_of_measured_node_mix_rate", valu["frac"])
+    if hbm_frac is not None and hbm_frac >= v_frac:
+        roof.update({"bound": "hbm", "achieved": mem["fabric_traffic_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac})
+    else:
+        roof.update({"bound": "valu_issue", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"], "frac": valu["frac"]})
+    return roof
 
 
 def spawn_ranks(n):
@@ -331,75 +422,7 @@ def main():
             lattice_parity = bool(frame_cpu[st_ // 2::st_, st_ // 2::st_].tobytes() == lat_img.tobytes())
         workload_key = f"g{args.grid}_{nx}x{ny}x{spp}_d{args.depth}"
         prof = committed_profile(workload_key)
-        # a counter pass taken from other sources than the ones that ran says nothing about this run: no fraction then
-        same_workload = prof.get("workload") == workload_key and world == 1 and not prof.get("profile_stale", True)
-        roof = {"kernel": "k_persistent<0,1,1,6,false> (render: quantized 4-wide nodes, speculative traversal, rounds)",
-                "kernel_ms": kernel_s * 1e3, "rays_per_launch": rays_per_launch,
-                "committed_profile": prof}
-        # Two units run near their limit in this kernel, both priced from the committed counter pass of
-        # these sources over THIS run's kernel time: the CUs' vector-memory data path (L1 tag accesses: every node
-        # visit of a lane is four 16-byte loads, and incoherent lanes share no line) and vector-instruction issue.
-        # The headline `bound` is the one nearer its peak.
-        L1_PEAK_GBS = 256 * 64 * PEAK_CLOCK_HZ / 1e9
-        if same_workload and "valu_insts_per_launch" in prof:
-            achieved = prof["valu_insts_per_launch"] / kernel_s / 1e9
-            peak = SIMDS * PEAK_CLOCK_HZ / VALU_ISSUE_CYCLES / 1e9
-            valu = {"achieved": achieved, "peak": peak, "unit": "G wave64-inst/s", "frac": achieved / peak,
-                    "basis": "SQ_INSTS_VALU per launch / kernel time; 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction",
-                    "lane_utilisation": prof.get("lane_utilisation"),
-                    "useful_lane_frac": achieved / peak * prof.get("lane_utilisation", 0.0),
-                    "waves_per_simd": prof.get("waves_per_simd")}
-            # against what a SIMD was MEASURED to issue (tools/micro/valu_rate.hip, 8 waves per SIMD): independent
-            # v_fma_f32, and the node test's own instruction mix -- the practical ceilings under the 2-cycle spec
-            try:
-                for line in open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_valu_issue_rate.jsonl")):
-                    t = json.loads(line)
-                    if t.get("waves_per_simd") == 8 and t.get("kind") in ("v_fma_f32", "node-test mix"):
-                        key = "frac_of_measured_fma_rate" if t["kind"] == "v_fma_f32" else "frac_of_measured_node_mix_rate"
-                        valu[key] = achieved / (SIMDS * PEAK_CLOCK_HZ / t["cycles_per_wave64_inst"] / 1e9)
-            except Exception:  # noqa: BLE001
-                pass
-            roof["valu_issue"] = valu
-            l1 = None
-            if "l1_accesses_per_launch" in prof:
-                a = prof["l1_accesses_per_launch"] * 64.0 / kernel_s / 1e9
-                l1 = {"achieved": a, "peak": L1_PEAK_GBS, "unit": "GB/s", "frac": a / L1_PEAK_GBS,
-                      "basis": "TCP_TOTAL_CACHE_ACCESSES x 64 B per launch / kernel time; peak = one L1 line access per cycle and CU x 256 CUs "
-                               "x 2.4 GHz, the ceiling tools/micro/l1_rate.hip measures (0.99 lane-loads per cycle and CU when every "
-                               "lane reads a 128-byte line of its own: profiles/r02_l1_rate.jsonl)",
-                      "accesses_per_cycle_per_cu_at_measured_clock": prof.get("l1_accesses_per_cycle_per_cu"),
-                      "td_busy_frac": prof.get("td_busy_frac"), "ta_busy_frac": prof.get("ta_busy_frac"),
-                      "l1_hit_rate": prof.get("l1_hit_rate"), "l2_hit_rate": prof.get("l2_hit_rate")}
-                roof["vector_l1"] = l1
-            if l1 is not None and l1["frac"] >= valu["frac"]:
-                roof.update({"bound": "vector_l1", "achieved": l1["achieved"], "peak": l1["peak"], "unit": "GB/s", "frac": l1["frac"]})
-            else:
-                roof.update({"bound": "valu_issue", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"], "frac": valu["frac"]})
-        else:
-            roof.update({"bound": "vector_l1", "achieved": None, "peak": L1_PEAK_GBS, "unit": "GB/s", "frac": None,
-                         "profile_stale": bool(prof.get("profile_stale", True)),
-                         "note": "no committed counter pass of these sources for this workload / rank count (profile_stale: the "
-                                 "kernel sources changed since the pass in profiles/ was taken): no fraction is claimed"})
-        # memory side, for reference (no fraction is claimed for HBM: at this scene size the caches serve nearly all of
-        # it): bytes the DEVICE tree makes a ray touch (64-B quantized node per visit, 48-B primitive per test, 28 B ray
-        # in + 8 B hit out; counts from the analysis build), the L2s' fabric traffic from the counter passes, and SURVEY
-        # 8d's figure for an ordered traversal of the reference's BINARY tree, counted live by the oracle on the CPU sample
-        mem = {"hbm_peak": HBM_PEAK_GBS, "unit": "GB/s"}
-        if "node_visits_per_ray" in prof:
-            dev_bytes = 64.0 * prof["node_visits_per_ray"] + 48.0 * prof["prim_tests_per_ray"] + 36.0
-            mem.update({"device_bytes_per_ray": dev_bytes, "device_bytes_rate_gbs": dev_bytes * rays_per_launch / kernel_s / 1e9,
-                        "node_visits_per_ray": prof["node_visits_per_ray"], "prim_tests_per_ray": prof["prim_tests_per_ray"]})
-        if same_workload and "fabric_bytes_per_launch" in prof:
-            mem["fabric_traffic_bytes_per_launch"] = prof["fabric_bytes_per_launch"]
-            mem["fabric_traffic_gbs"] = prof["fabric_bytes_per_launch"] / kernel_s / 1e9
-            mem["fabric_traffic_share_of_hbm_peak"] = mem["fabric_traffic_gbs"] / HBM_PEAK_GBS
-            mem["fabric_traffic_note"] = "L2-side fabric requests, Infinity-Cache hits included: an upper bound on HBM bytes"
-        if bytes_per_ray is not None:
-            mem["algorithmic_bytes_per_ray_binary_tree"] = bytes_per_ray
-            mem["binary_tree_rate_gbs"] = bytes_per_ray * rays_per_launch / kernel_s / 1e9
-            mem["binary_tree_note"] = "SURVEY 8d's model; it does not describe this kernel (16 visits of 64-B wide nodes per ray, not 571 box tests)"
-        roof["hbm"] = mem
-        roof["traffic"] = mem.get("fabric_traffic_bytes_per_launch")
+        roof = roofline_of(prof, workload_key, world, kernel_s, rays_per_launch, bytes_per_ray)
         line = {
             "metric": "Mrays/s (node) on 1M-tri BVH; ms/frame at 1080p",
             "value": value,
