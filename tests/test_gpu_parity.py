@@ -160,10 +160,12 @@ def test_collapse_by_cost_same_results(oracle, scene, leaf):
     assert counts[1] <= counts[0]
 
 
-def test_trace_rays_incoherent(oracle):
-    """Incoherent rays (bounce-like): random origins above the surface, random directions."""
+@pytest.mark.parametrize("fmt", [1, 2])
+def test_trace_rays_incoherent(oracle, fmt):
+    """Incoherent rays (bounce-like): random origins above the surface, random directions; through the quantised nodes
+    and through the packed scene (k_trace_queue<1> / <2>)."""
     tris = scenes.heightfield(96)
-    eng = _engine(tris, 64, 64, 1, 8, scenes.BENCH_CAMERA)
+    eng = _engine(tris, 64, 64, 1, 8, scenes.BENCH_CAMERA, {engine.OPT_NODE_FORMAT: fmt})
     nodes = eng.getBvhNodes()
     rs = np.random.RandomState(9)
     n = 20000
@@ -530,10 +532,12 @@ def test_trace_rays_device_equals_host_path_and_oracle(oracle, thr, n, qw):
     eng.close()
 
 
+@pytest.mark.parametrize("fmt", [1, 2])
 @pytest.mark.parametrize("n_extra,nx,ny,ns", [(0, 17, 9, 3), (1, 1, 1, 5), (2, 8, 8, 1), (5, 33, 2, 9)])
-def test_tiny_scenes_and_frames(oracle, n_extra, nx, ny, ns):
+def test_tiny_scenes_and_frames(oracle, n_extra, nx, ny, ns, fmt):
     """The small end: one, two, three and six primitives (a one-node tree; leaves that are the whole scene), frames of
-    one pixel / one tile / a sliver, a sample count below the round count -- image and hit ids still the oracle's."""
+    one pixel / one tile / a sliver, a sample count below the round count -- image and hit ids still the oracle's, with
+    the quantised nodes and with the packed scene (whose root block is then all there is)."""
     v = np.array([[4, 10, -4], [-4, 10, -4], [-4, 10, 4], [4, 10, 4]], dtype=np.float32)
     parts = [scenes.make_triangles(v[[3]], v[[2]], v[[1]], 3)]
     if n_extra >= 1:
@@ -545,7 +549,7 @@ def test_tiny_scenes_and_frames(oracle, n_extra, nx, ny, ns):
         parts.append(scenes.make_spheres(np.array([[2, 0.5, 1], [-2, 0.5, 1], [0, 0.5, 3]], np.float32), [0.5, 0.5, 0.5], 4))
     tris = np.concatenate(parts)
     cam = dict(lookfrom=[3, 2.5, 9], lookat=[0, 1, 0], vfov=40.0, dist_to_focus=9.0, aperture=0.1)
-    eng = _engine(tris, nx, ny, ns, 10, cam)
+    eng = _engine(tris, nx, ny, ns, 10, cam, {engine.OPT_NODE_FORMAT: fmt})
     fb = eng.render()
     rays = eng.last_stats.rays
     ids, ts = eng.tracePrimary()
@@ -750,6 +754,13 @@ def test_bench_frame_64spp_lattice(oracle):
     one_round = eng.render()
     assert eng.last_stats.rays == rays
     assert one_round.tobytes() == fb.tobytes()
+    # and through the packed scene (RT_OPT_NODE_FORMAT 2: other records, other addresses, the same boxes and primitives):
+    # the same 288 M rays, the same frame
+    eng.setOption(engine.OPT_TAIL_SPLIT, 0)
+    eng.setOption(engine.OPT_NODE_FORMAT, 2)
+    packed = eng.render()
+    assert eng.last_stats.rays == rays
+    assert packed.tobytes() == fb.tobytes()
     eng.close()
 
 
