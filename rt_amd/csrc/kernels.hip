@@ -179,9 +179,10 @@ __device__ __forceinline__ Hit closest_hit(const float4 *__restrict__ nodes, con
     const float idx = safe_inv(r.d.x), idy = safe_inv(r.d.y), idz = safe_inv(r.d.z);
     const float nox = -r.o.x * idx, noy = -r.o.y * idy, noz = -r.o.z * idz;
     // near / far plane vectors by direction sign (float4 index inside the node)
-    const int nxi = r.d.x < 0.0f ? 3 : 0, fxi = 3 - nxi;
-    const int nyi = r.d.y < 0.0f ? 4 : 1, fyi = 5 - nyi;
-    const int nzi = r.d.z < 0.0f ? 5 : 2, fzi = 7 - nzi;
+    // (by the sign of the reciprocal: -0 counts as negative, as aabb::hit's `invD < 0` has it, triangle.h:52-70)
+    const int nxi = idx < 0.0f ? 3 : 0, fxi = 3 - nxi;
+    const int nyi = idy < 0.0f ? 4 : 1, fyi = 5 - nyi;
+    const int nzi = idz < 0.0f ? 5 : 2, fzi = 7 - nzi;
 
     float best_t = FLT_MAX;
     int best_rank = RT_NO_HIT;
@@ -699,9 +700,11 @@ __device__ __forceinline__ void trav_begin(Trav &T, const Ray &r, uint32_t sp0) 
     T.nox = -r.o.x * T.idx;
     T.noy = -r.o.y * T.idy;
     T.noz = -r.o.z * T.idz;
-    T.nxi = r.d.x < 0.0f ? 3 : 0;
-    T.nyi = r.d.y < 0.0f ? 4 : 1;
-    T.nzi = r.d.z < 0.0f ? 5 : 2;
+    // float nodes only (the other formats take the sign of idx / idy / idz in the node step): near-plane vector by the
+    // sign of the RECIPROCAL direction, so that -0 goes with the negative components, as aabb::hit's `invD < 0` has it
+    T.nxi = T.idx < 0.0f ? 3 : 0;
+    T.nyi = T.idy < 0.0f ? 4 : 1;
+    T.nzi = T.idz < 0.0f ? 5 : 2;
     T.best_t = FLT_MAX;
     T.cull_t = FLT_MAX;
     T.best_rank = RT_NO_HIT;
@@ -926,7 +929,9 @@ __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const S
             const float ax = __builtin_fmaf(__uint_as_float(h.x), T.idx, T.nox);
             const float ay = __builtin_fmaf(__uint_as_float(h.y), T.idy, T.noy);
             const float az = __builtin_fmaf(__uint_as_float(h.z), T.idz, T.noz);
-            const bool ngx = T.nxi != 0, ngy = T.nyi != 1, ngz = T.nzi != 2;
+            // near / far by the sign of the reciprocal direction (-0 counts as negative, as aabb::hit's `invD < 0` does):
+            // three registers fewer than carrying the plane indices of the float-node format
+            const bool ngx = T.idx < 0.0f, ngy = T.idy < 0.0f, ngz = T.idz < 0.0f;
             const uint32_t nqx = ngx ? qa.y : qa.x, fqx = ngx ? qa.x : qa.y;
             const uint32_t nqy = ngy ? qa.w : qa.z, fqy = ngy ? qa.z : qa.w;
             const uint32_t nqz = ngz ? qb.y : qb.x, fqz = ngz ? qb.x : qb.y;
@@ -962,7 +967,9 @@ __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const S
             const float ax = __builtin_fmaf(__uint_as_float(h.x), T.idx, T.nox);
             const float ay = __builtin_fmaf(__uint_as_float(h.y), T.idy, T.noy);
             const float az = __builtin_fmaf(__uint_as_float(h.z), T.idz, T.noz);
-            const bool ngx = T.nxi != 0, ngy = T.nyi != 1, ngz = T.nzi != 2;
+            // near / far by the sign of the reciprocal direction (-0 counts as negative, as aabb::hit's `invD < 0` does):
+            // three registers fewer than carrying the plane indices of the float-node format
+            const bool ngx = T.idx < 0.0f, ngy = T.idy < 0.0f, ngz = T.idz < 0.0f;
             const uint32_t nqx = ngx ? qa.y : qa.x, fqx = ngx ? qa.x : qa.y;
             const uint32_t nqy = ngy ? qa.w : qa.z, fqy = ngy ? qa.z : qa.w;
             const uint32_t nqz = ngz ? qb.y : qb.x, fqz = ngz ? qb.x : qb.y;

@@ -189,6 +189,34 @@ def test_trace_rays_incoherent(oracle, fmt):
     eng.close()
 
 
+@pytest.mark.parametrize("fmt,kernel", [(1, 2), (2, 2), (1, 1), (0, 1), (0, 0)])
+def test_negative_zero_direction_components(oracle, fmt, kernel):
+    """A direction component of -0.0: aabb::hit's `invD < 0` (triangle.h:52-70) is true for 1 / -0 = -inf, so the
+    reference swaps the slab's planes as for any negative component.  The box test here picks near / far planes by the
+    sign of the reciprocal direction, so -0 goes the same way (picking them by `d < 0`, which is false for -0, made the
+    slab's interval empty for a ray INSIDE the slab and the ray missed everything behind it)."""
+    tris = scenes.heightfield(64)
+    eng = _engine(tris, 32, 32, 1, 8, scenes.BENCH_CAMERA, {engine.OPT_NODE_FORMAT: fmt, engine.OPT_KERNEL: kernel})
+    nodes = eng.getBvhNodes()
+    rs = np.random.RandomState(3)
+    n = 3000
+    org = rs.uniform((-9, 1.5, -9), (9, 6, 9), size=(n, 3)).astype(np.float32)
+    d = rs.normal(size=(n, 3)).astype(np.float32)
+    d[:, 1] = -np.abs(d[:, 1])
+    d[0::3, 0] = np.float32(-0.0)
+    d[1::3, 2] = np.float32(-0.0)
+    d[2::9, 0] = np.float32(-0.0)
+    d[2::9, 2] = np.float32(-0.0)  # straight down, both horizontal components -0
+    ids, ts = eng.traceRays(np.concatenate([org, d], axis=1))
+    hits = 0
+    for k in range(0, n, 5):
+        h, i, t, _ = oracle.hit(tris, nodes, org[k], d[k], "reference")
+        assert ids[k] == (i if h else -1) and (not h or np.float32(t) == ts[k]), k
+        hits += int(h)
+    assert hits > 300
+    eng.close()
+
+
 @pytest.mark.parametrize("leaf,box_mode,topo", [(1, 0, 0), (2, 1, 0), (8, 0, 0), (4, 1, 0), (4, 0, 1), (2, 1, 1)])
 def test_device_layout_options_do_not_change_results(leaf, box_mode, topo):
     tris = scenes.heightfield(40)
