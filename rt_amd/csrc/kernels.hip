@@ -158,6 +158,22 @@ __device__ __forceinline__ float safe_inv(float d) {
     return inv;
 }
 
+// Box tests for rays of ANY direction length (rt_trace_rays takes what the caller hands it; the reference does not
+// normalise directions either).  The reciprocal direction is capped at 1e18 per component (safe_inv), which is harmless
+// for a component that is tiny beside the others and wrong when ALL of them are tiny: the three slabs' intervals are
+// then scaled by different factors and stop overlapping.  So the box tests of the ray-array kernels run on the
+// direction scaled by a power of two that brings its largest component into [0.5, 1): d' = d * 2^-e, t' = t * 2^e.
+// Exact (powers of two), and it touches nothing parity-critical: primitive tests take the ray as it came.
+// Returns 2^e (e clamped to +-100, 0 for a zero or non-finite direction); `to_unit` = 2^-e.
+__device__ __forceinline__ float dir_scale(const V3 &d, float &to_unit) {
+    const float m = fmaxf(fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    int e = 0;
+    if (m > 0.0f && m < __builtin_inff()) e = (int)((__float_as_uint(m) >> 23) & 0xFFu) - 126; // m = f * 2^e, f in [0.5, 1)
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    to_unit = __uint_as_float((uint32_t)(127 - e) << 23);
+    return __uint_as_float((uint32_t)(127 + e) << 23);
+}
+
 __device__ __forceinline__ uint32_t sel4(uint4 c, uint32_t s) {
     uint32_t lo = (s & 1) ? c.y : c.x;
     uint32_t hi = (s & 1) ? c.w : c.z;
@@ -176,7 +192,10 @@ __device__ __forceinline__ uint32_t sel4(uint4 c, uint32_t s) {
 // stack: this lane's column; entry k lives at stack[k * 64].
 __device__ __forceinline__ Hit closest_hit(const float4 *__restrict__ nodes, const float4 *__restrict__ prims,
                                            const Ray &r, uint32_t *stack) {
-    const float idx = safe_inv(r.d.x), idy = safe_inv(r.d.y), idz = safe_inv(r.d.z);
+    float to_unit;
+    const float ts = dir_scale(r.d, to_unit); // box distances below are t * ts (see dir_scale)
+    const float tmin_s = 0.001f * ts;
+    const float idx = safe_inv(r.d.x * to_unit), idy = safe_inv(r.d.y * to_unit), idz = safe_inv(r.d.z * to_unit);
     const float nox = -r.o.x * idx, noy = -r.o.y * idy, noz = -r.o.z * idz;
     // near / far plane vectors by direction sign (float4 index inside the node)
     // (by the sign of the reciprocal: -0 counts as negative, as aabb::hit's `invD < 0` has it, triangle.h:52-70)
@@ -198,9 +217,9 @@ __device__ __forceinline__ Hit closest_hit(const float4 *__restrict__ nodes, con
 #define RT_SLAB(K, C, I)                                                                                               \
     {                                                                                                                  \
         float tn = fmaxf(fmaxf(__builtin_fmaf(nx.C, idx, nox), __builtin_fmaf(ny.C, idy, noy)),                        \
-                         fmaxf(__builtin_fmaf(nz.C, idz, noz), 0.001f));                                               \
+                         fmaxf(__builtin_fmaf(nz.C, idz, noz), tmin_s));                                               \
         float tf = fminf(fminf(__builtin_fmaf(fx.C, idx, nox), __builtin_fmaf(fy.C, idy, noy)),                        \
-                         fminf(__builtin_fmaf(fz.C, idz, noz), best_t));                                               \
+                         fminf(__builtin_fmaf(fz.C, idz, noz), best_t * ts));                                          \
         K = (tn <= tf) ? ((__float_as_uint(tn) & ~3u) | I) : 0xFFFFFFFFu;                                              \
     }
             RT_SLAB(k0, x, 0u)
@@ -677,10 +696,14 @@ template <int FMT> __device__ __forceinline__ int hit_record_index(int best_rank
     return (int)(__umulhi((uint32_t)best_rank, 0xAAAAAAABu) >> 1); // unit / 3, exact below 2^31
 }
 
-#define RT_CULL_T(T) (DET ? (T).cull_t : (T).best_t)
+// SCALED (ray-array kernels): box distances are t * T.ts (dir_scale above); the render kernels' rays are of ordinary
+// length by construction (camera, scatter) and keep the plain constants.
+#define RT_SCALED_T(T, V) (SCALED ? (V) * (T).ts : (V))
+#define RT_CULL_T(T) (DET ? (T).cull_t : RT_SCALED_T(T, (T).best_t))
+#define RT_TMIN(T) (SCALED ? (T).tmin : 0.001f)
 #define RT_CULL_SYNC(T)                                                                                                \
     do {                                                                                                               \
-        if (DET) (T).cull_t = (T).best_t;                                                                              \
+        if (DET) (T).cull_t = RT_SCALED_T(T, (T).best_t);                                                              \
     } while (0)
 struct Trav {
     float idx, idy, idz, nox, noy, noz;
@@ -691,12 +714,17 @@ struct Trav {
     uint32_t cur;
     uint32_t pend; // speculative traversal: one postponed leaf
     uint32_t sp;   // LDS address of the next free stack entry of this lane: stack base + entry * 256 + lane * 4
+    float ts, tmin; // SCALED only: box distances are t * ts; tmin = 0.001 * ts
 };
 
+template <bool SCALED = false>
 __device__ __forceinline__ void trav_begin(Trav &T, const Ray &r, uint32_t sp0) {
-    T.idx = safe_inv(r.d.x);
-    T.idy = safe_inv(r.d.y);
-    T.idz = safe_inv(r.d.z);
+    float to_unit = 1.0f;
+    T.ts = SCALED ? dir_scale(r.d, to_unit) : 1.0f;
+    T.tmin = 0.001f * T.ts;
+    T.idx = safe_inv(SCALED ? r.d.x * to_unit : r.d.x);
+    T.idy = safe_inv(SCALED ? r.d.y * to_unit : r.d.y);
+    T.idz = safe_inv(SCALED ? r.d.z * to_unit : r.d.z);
     T.nox = -r.o.x * T.idx;
     T.noy = -r.o.y * T.idy;
     T.noz = -r.o.z * T.idz;
@@ -887,7 +915,7 @@ __device__ __forceinline__ uint32_t pop_or_none(const StackRef &K, uint32_t &sp)
 // one wide node: tests its four child boxes, sets T.cur to the nearest hit child (pushing the others) or to the
 // next stack entry (RT_REF_NONE when the stack is empty).
 // FMT 0: 128-byte float nodes (WideNode).  FMT 1: 64-byte quantized nodes (QuantNode).
-template <int FMT, bool DET>
+template <int FMT, bool DET, bool SCALED = false>
 __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const StackRef &K) {
     // every stack entry this step can touch is in LDS (entries [e - 1, e + 2] for a stack of e): the common case
     const bool fast = T.sp < K.fast_limit;
@@ -902,7 +930,7 @@ __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const S
 #define RT_SLAB(K_, C, I)                                                                                              \
     {                                                                                                                  \
         float tn = fmaxf(fmaxf(__builtin_fmaf(nx.C, T.idx, T.nox), __builtin_fmaf(ny.C, T.idy, T.noy)),                \
-                         fmaxf(__builtin_fmaf(nz.C, T.idz, T.noz), 0.001f));                                           \
+                         fmaxf(__builtin_fmaf(nz.C, T.idz, T.noz), RT_TMIN(T)));                                       \
         float tf = fminf(fminf(__builtin_fmaf(fx.C, T.idx, T.nox), __builtin_fmaf(fy.C, T.idy, T.noy)),                \
                          fminf(__builtin_fmaf(fz.C, T.idz, T.noz), RT_CULL_T(T)));                                         \
         K_ = (tn <= tf) ? RT_KEY(tn, I) : 0xFFFFFFFFu;                                                                 \
@@ -943,7 +971,7 @@ __device__ __forceinline__ void node_step(Trav &T, const KernelScene &S, const S
 #define RT_SLABQ(K_, SH, I, KEYF)                                                                                         \
     {                                                                                                                  \
         float tn = fmaxf(fmaxf(__builtin_fmaf(RT_QB(nqx, SH), sx, ax), __builtin_fmaf(RT_QB(nqy, SH), sy, ay)),        \
-                         fmaxf(__builtin_fmaf(RT_QB(nqz, SH), sz, az), 0.001f));                                       \
+                         fmaxf(__builtin_fmaf(RT_QB(nqz, SH), sz, az), RT_TMIN(T)));                                   \
         float tf = fminf(fminf(__builtin_fmaf(RT_QB(fqx, SH), sx, ax), __builtin_fmaf(RT_QB(fqy, SH), sy, ay)),        \
                          fminf(__builtin_fmaf(RT_QB(fqz, SH), sz, az), RT_CULL_T(T)));                                     \
         K_ = (tn <= tf) ? KEYF(tn, I) : 0xFFFFFFFFu;                                                                   \
@@ -1124,6 +1152,7 @@ __device__ __forceinline__ void leaf_fire(Trav &T, const KernelScene &S, const R
 template <int FMT>
 __device__ __forceinline__ bool trav_step(Trav &T, const KernelScene &S, const Ray &r, const StackRef &K) {
     constexpr bool DET = true; // leaves are tested where they are reached: the value culled against is always current
+    constexpr bool SCALED = false;
     if (!ref_is_leaf<FMT>(T.cur)) {
         node_step<FMT, DET>(T, S, K);
     } else {
@@ -1275,6 +1304,7 @@ typedef __attribute__((address_space(4))) const KArgs CKArgs;
 template <int MODE, int FMT, int SPEC, int OCC, bool TEX, bool DET>
 __global__ void __launch_bounds__(64, OCC) k_persistent(KernelScene S, KernelFrame F, PersistArgs P, float *fb, int32_t *ids,
                                                    float *ts) {
+    constexpr bool SCALED = false; // camera rays and scattered rays are of ordinary length by construction
     const uint32_t lane = threadIdx.x;
     StackRef K;
     stack_ref_init(K, lane, P.spill, P.lds_entries, P.total_lanes);
@@ -1604,6 +1634,7 @@ struct QueueArgs {
 };
 template <int FMT, bool DET>
 __global__ void __launch_bounds__(64, 6) k_trace_queue(KernelScene S, PersistArgs P, QueueArgs Q) {
+    constexpr bool SCALED = true; // the caller's rays: any direction length (dir_scale)
     const uint32_t lane = threadIdx.x;
     StackRef K;
     stack_ref_init(K, lane, P.spill, P.lds_entries, P.total_lanes);
@@ -1615,7 +1646,7 @@ __global__ void __launch_bounds__(64, 6) k_trace_queue(KernelScene S, PersistArg
     cur.o = mk(0, 0, 0);
     cur.d = mk(0, 0, 1);
     Trav T;
-    trav_begin(T, cur, K.sp0);
+    trav_begin<SCALED>(T, cur, K.sp0);
     for (;;) {
         // ---- hand out rays to the idle lanes
         for (int guard = 0; guard < 4; guard++) {
@@ -1640,7 +1671,7 @@ __global__ void __launch_bounds__(64, 6) k_trace_queue(KernelScene S, PersistArg
                 const float2 a = r[0], b = r[1], c = r[2];
                 cur.o = mk(a.x, a.y, b.x);
                 cur.d = mk(b.y, c.x, c.y);
-                trav_begin(T, cur, K.sp0);
+                trav_begin<SCALED>(T, cur, K.sp0);
                 tracing = true;
                 nr++;
             }
@@ -1654,7 +1685,7 @@ __global__ void __launch_bounds__(64, 6) k_trace_queue(KernelScene S, PersistArg
             const unsigned long long act = ballot(tracing);
             if (act == 0ull) break;
             if (!exhausted && (int)__popcll(act) < P.threshold) break;
-            if (tracing && !ref_is_leaf<FMT>(T.cur)) node_step<FMT, DET>(T, S, K);
+            if (tracing && !ref_is_leaf<FMT>(T.cur)) node_step<FMT, DET, SCALED>(T, S, K);
             if (tracing && T.pend == RT_REF_NONE && T.cur != RT_REF_NONE && ref_is_leaf<FMT>(T.cur)) {
                 T.pend = T.cur;
                     RT_CULL_SYNC(T); // every leaf parked before this one has been tested by now

@@ -217,6 +217,36 @@ def test_negative_zero_direction_components(oracle, fmt, kernel):
     eng.close()
 
 
+@pytest.mark.parametrize("fmt,kernel", [(1, 2), (2, 2), (1, 1), (0, 0)])
+def test_unusual_ray_directions(oracle, fmt, kernel):
+    """rt_trace_rays takes the caller's rays as they are, and the reference normalises nothing: directions of length
+    1e-36 .. 1e10, one component 1e-12 of the others, denormal and zero components.  The box tests of the ray-array
+    kernels run on the direction scaled by a power of two (kernels.hip dir_scale: with the reciprocal capped per
+    component, a direction whose components are ALL tiny had its three slab intervals scaled apart and missed
+    everything); ids and t are the oracle's, bit for bit (t up to 1e37 and all)."""
+    rs = np.random.RandomState(11)
+    for tris in (scenes.heightfield(40), scenes.spheres_scene()):
+        eng = _engine(tris, 32, 32, 1, 8, scenes.BENCH_CAMERA, {engine.OPT_NODE_FORMAT: fmt, engine.OPT_KERNEL: kernel})
+        nodes = eng.getBvhNodes()
+        n = 1200
+        org = rs.uniform((-9, 0.5, -9), (9, 6, 9), size=(n, 3)).astype(np.float32)
+        d = rs.normal(size=(n, 3)).astype(np.float32)
+        d[:, 1] = -np.abs(d[:, 1])
+        scale = np.float32([1e-36, 1e-30, 1e-20, 1e-9, 1e10, 1.0])[np.arange(n) % 6]
+        d = (d * scale[:, None]).astype(np.float32)
+        d[6::12, 0] *= np.float32(1e-12)                # one component far below the others
+        d[7::12, 2] = np.float32(1e-45)                 # the smallest denormal
+        d[8::24, 0] = 0.0
+        ids, ts = eng.traceRays(np.concatenate([org, d], axis=1))
+        hits = 0
+        for k in range(0, n, 3):
+            h, i, t, _ = oracle.hit(tris, nodes, org[k], d[k], "reference")
+            assert ids[k] == (i if h else -1) and (not h or np.float32(t) == ts[k]), (k, d[k].tolist())
+            hits += int(h)
+        assert hits > 150  # (directions of length 1e10 hit nothing: every t is below the reference's 0.001)
+        eng.close()
+
+
 @pytest.mark.parametrize("leaf,box_mode,topo", [(1, 0, 0), (2, 1, 0), (8, 0, 0), (4, 1, 0), (4, 0, 1), (2, 1, 1)])
 def test_device_layout_options_do_not_change_results(leaf, box_mode, topo):
     tris = scenes.heightfield(40)
