@@ -5,6 +5,7 @@ are float32 produced by the same operation sequence without FMA; SURVEY.md secti
 therefore met with margin: the difference is exactly 0.
 """
 import hashlib
+import itertools
 import json
 import os
 
@@ -244,6 +245,29 @@ def test_unusual_ray_directions(oracle, fmt, kernel):
             assert ids[k] == (i if h else -1) and (not h or np.float32(t) == ts[k]), (k, d[k].tolist())
             hits += int(h)
         assert hits > 150  # (directions of length 1e10 hit nothing: every t is below the reference's 0.001)
+        eng.close()
+
+
+@pytest.mark.parametrize("kernel,fmt", [(2, 1), (2, 2), (0, 0)])
+def test_unusual_scenes_bit_exact(oracle, kernel, fmt):
+    """Scenes that stress the closest-hit rule rather than the traversal speed (tools/edge_scenes.py): exact
+    duplicates of 300 triangles and a reversed copy (every hit is a three-way tie: the lower DFS-leaf rank of the
+    REFERENCE tree must win, pbrt_engine.cu:421-438), coplanar overlapping quads, five coincident ground planes, long thin
+    triangles, a 2 cm cluster and a cluster 3 km away in one scene (grid exponents from 2^-20 to 2^4), touching and
+    nested spheres; a camera outside and one inside the cluster with a lens.  Image, hit ids and t are the oracle's."""
+    from tools import edge_scenes
+
+    nx, ny, ns, depth = 48, 27, 3, 10
+    for (name, tris), (cname, cam) in itertools.product(edge_scenes.build_cases().items(), edge_scenes.CAMS.items()):
+        eng = _engine(tris, nx, ny, ns, depth, cam, {engine.OPT_KERNEL: kernel, engine.OPT_NODE_FORMAT: fmt})
+        fb = eng.render()
+        ids, ts = eng.tracePrimary()
+        nodes = eng.getBvhNodes()
+        ocam = oracle.camera(cam["lookfrom"], cam["lookat"], 40.0, nx / ny, cam["aperture"], cam["dist_to_focus"])
+        fb_o, cnt = oracle.render(tris, nodes, oracle.material_table(), ocam, nx, ny, ns, depth, mode=0)
+        ids_o, ts_o, _ = oracle.trace_primary(tris, nodes, ocam, nx, ny, mode=0)
+        assert eng.last_stats.rays > 0 and fb.tobytes() == fb_o.tobytes(), (name, cname)
+        assert ids.tobytes() == ids_o.tobytes() and ts.tobytes() == ts_o.tobytes(), (name, cname)
         eng.close()
 
 
