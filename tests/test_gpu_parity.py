@@ -271,6 +271,45 @@ def test_unusual_scenes_bit_exact(oracle, kernel, fmt):
         eng.close()
 
 
+@pytest.mark.parametrize("kernel,fmt", [(2, 1), (2, 2), (0, 0)])
+def test_material_tables_and_cameras_off_the_beaten_path(oracle, kernel, fmt):
+    """rt_set_materials with tables the default one never exercises (tools/edge_materials.py: random kinds, albedos
+    beyond 1 and of 1e-30, fuzz 0 .. 2 and negative, refraction indices 0.3 .. 3 and exactly 1, a world of mirrors and
+    glass only) at depth 40, and cameras the tests above never use: a lens wider than the scene's spheres, a focus
+    distance of 1 cm, an eye inside the glass sphere, an eye on the ground plane, the vertical field of view honoured
+    (RT_OPT_HONOR_VFOV; the reference ignores it).  Image and ray count are the oracle's."""
+    from tools import edge_materials
+
+    nx, ny, ns, depth = 48, 27, 4, 40
+    tris = scenes.spheres_scene()
+    for mname, mats in edge_materials.tables().items():
+        cam = scenes.DEFAULT_CAMERA
+        eng = _engine(tris, nx, ny, ns, depth, cam, {engine.OPT_KERNEL: kernel, engine.OPT_NODE_FORMAT: fmt})
+        eng.setMaterials(mats)
+        fb = eng.render()
+        ocam = oracle.camera(cam["lookfrom"], cam["lookat"], 40.0, nx / ny, cam["aperture"], cam["dist_to_focus"])
+        fb_o, cnt = oracle.render(tris, eng.getBvhNodes(), mats, ocam, nx, ny, ns, depth, mode=1)
+        assert eng.last_stats.rays == cnt.rays and fb.tobytes() == fb_o.tobytes(), mname
+        eng.close()
+    cams = {"wide lens": dict(lookfrom=[6, 2, 5], lookat=[0, 1, 0], vfov=40.0, dist_to_focus=7.0, aperture=3.0),
+            "focus at 1 cm": dict(lookfrom=[6, 2, 5], lookat=[0, 1, 0], vfov=40.0, dist_to_focus=0.01, aperture=0.5),
+            "inside the glass sphere": dict(lookfrom=[0.2, 1.1, 0.1], lookat=[4, 1, 0], vfov=40.0, dist_to_focus=3.0, aperture=0.0),
+            "eye on the ground": dict(lookfrom=[9, 0.0, 9], lookat=[0, 0.5, 0], vfov=40.0, dist_to_focus=10.0, aperture=0.0),
+            "vfov 75 honoured": dict(lookfrom=[13, 2, 3], lookat=[0, 0, 0], vfov=75.0, dist_to_focus=10.0, aperture=0.1)}
+    for cname, cam in cams.items():
+        honour = cname.startswith("vfov")
+        eng = _engine(tris, nx, ny, ns, 12, cam, {engine.OPT_KERNEL: kernel, engine.OPT_NODE_FORMAT: fmt, engine.OPT_HONOR_VFOV: int(honour)})
+        fb = eng.render()
+        ids, ts = eng.tracePrimary()
+        nodes = eng.getBvhNodes()
+        ocam = oracle.camera(cam["lookfrom"], cam["lookat"], cam["vfov"] if honour else 40.0, nx / ny, cam["aperture"], cam["dist_to_focus"])
+        fb_o, cnt = oracle.render(tris, nodes, oracle.material_table(), ocam, nx, ny, ns, 12, mode=1)
+        ids_o, ts_o, _ = oracle.trace_primary(tris, nodes, ocam, nx, ny, mode=1)
+        assert eng.last_stats.rays > 0 and fb.tobytes() == fb_o.tobytes(), cname
+        assert ids.tobytes() == ids_o.tobytes() and ts.tobytes() == ts_o.tobytes(), cname
+        eng.close()
+
+
 @pytest.mark.parametrize("leaf,box_mode,topo", [(1, 0, 0), (2, 1, 0), (8, 0, 0), (4, 1, 0), (4, 0, 1), (2, 1, 1)])
 def test_device_layout_options_do_not_change_results(leaf, box_mode, topo):
     tris = scenes.heightfield(40)
