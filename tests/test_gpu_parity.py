@@ -709,6 +709,35 @@ def _textured_scene():
     ])
 
 
+@pytest.mark.parametrize("kernel,fmt", [(2, 1), (2, 2), (0, 0)])
+def test_texture_coordinates_and_sizes_off_the_beaten_path(oracle, kernel, fmt):
+    """tools/edge_textures.py: texture coordinates that are negative, beyond 1, of magnitude 1e7 and 1e30, denormal,
+    NaN and infinite, and exactly on texel borders; textures of 1 x 1, 257 x 3, 2 x 64 and 2 x 2 texels; a sphere and a
+    metal wall that name a texture (ignored, triangle.h:207, material.h:163-171); a textured light.  The shared
+    restatement of tex2D gives the oracle's image on every variant."""
+    from tools import edge_textures
+
+    cam = dict(lookfrom=[3, 4, 11], lookat=[0, 1.5, 0], vfov=40.0, dist_to_focus=10.0, aperture=0.0)
+    nx, ny, ns, depth = 48, 27, 3, 8
+    tex = edge_textures.textures()
+    for i, t in tex.items():
+        oracle.set_texture(i, t)
+    images = set()
+    for kind in edge_textures.scene("huge")[1]:
+        tris, _ = edge_textures.scene(kind)
+        eng = _engine(tris, nx, ny, ns, depth, cam, {engine.OPT_KERNEL: kernel, engine.OPT_NODE_FORMAT: fmt})
+        for i, t in tex.items():
+            eng.setTexture(i, t)
+        fb = eng.render()
+        ocam = oracle.camera(cam["lookfrom"], cam["lookat"], 40.0, nx / ny, 0.0, 10.0)
+        fb_o, cnt = oracle.render(tris, eng.getBvhNodes(), oracle.material_table(), ocam, nx, ny, ns, depth, mode=1)
+        assert eng.last_stats.rays == cnt.rays and fb.tobytes() == fb_o.tobytes(), kind
+        assert np.isfinite(fb).all(), kind
+        images.add(fb.tobytes())
+        eng.close()
+    assert len(images) >= 4  # the coordinates do reach the picture
+
+
 @pytest.mark.parametrize("kernel,fmt,topo", [(2, 1, 1), (1, 0, 0), (0, 0, 1), (2, 2, 1), (2, 2, 0)])  # format 2: texture coordinates by record number
 def test_textured_lambertian_bit_exact(oracle, kernel, fmt, topo):
     """lambertian albedo and light emission from a texture (material.h:100-106, 140-146) -- RGBA8 set through rt_set_texture,
