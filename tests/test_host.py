@@ -330,6 +330,23 @@ def test_packed_scene_is_the_quantized_tree(leaf, topology):
     assert engine.host_pack_layout(tris, engine.host_build_bvh(tris), 4, 3) is None  # leaves of up to four primitives
 
 
+def test_host_builder_bit_exact_on_ties(oracle):
+    """make_bvh_nodes sorts by padded box corners with std::sort, whose order among EQUAL keys is whatever introsort
+    leaves (median-of-three, unguarded partition, insertion sort below 16, heapsort past the depth limit): the restated
+    sort must leave the same one.  Scenes made of ties: tools/edge_scenes.py (exact duplicates, coincident planes), a
+    heightfield five times over, 3 000 identical triangles (every key equal at every level), and 135 000 records with
+    three copies of each triangle (the parallel builder's subtrees)."""
+    from tools import edge_scenes
+
+    cases = dict(edge_scenes.build_cases())
+    cases["heightfield x 5"] = np.concatenate([scenes.heightfield(30)] * 5)
+    one = scenes.make_triangles(np.float32([[1, 2, 3]]), np.float32([[2, 2, 3]]), np.float32([[1, 3, 3]]), 0)
+    cases["3000 identical"] = np.concatenate([scenes.light_quad(), np.repeat(one, 3000)])
+    cases["135 k, every triangle three times"] = np.concatenate([scenes.heightfield(150)] * 3)
+    for name, tris in cases.items():
+        assert engine.host_build_bvh(tris).tobytes() == oracle.build_bvh(tris).tobytes(), name
+
+
 def test_wide_layout_rejects_malformed_tree():
     tris = scenes.heightfield(4)
     nodes = engine.host_build_bvh(tris)
