@@ -1005,7 +1005,7 @@ def test_cfg4_4k_frame_tile_sharded(oracle):
     eng.close()
 
 
-@pytest.mark.parametrize("flags,fmt,kernel", [(0, 1, 2), (3, 0, 1), (1, 0, 0)])
+@pytest.mark.parametrize("flags,fmt,kernel", [(0, 1, 2), (3, 0, 1), (1, 0, 0), (0, 2, 2)])  # format 2 on an imported scene runs format 1
 def test_export_import_scene(oracle, tmp_path, flags, fmt, kernel):
     """rt_export_scene / rt_import_scene: a context that only imports the block another context built -- here through
     a file mapping, as ranks of one node share it -- renders the same frame and primary hits, bit for bit, and the
